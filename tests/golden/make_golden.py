@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE'S OWN FUNCTIONS.
+
+Run in the build container only (needs /root/reference, which never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference cannot be imported as shipped here: Biopython, scoop and h5py are absent and
+`sklearn.externals.joblib` no longer exists (ordinary ModuleNotFoundError).
+This harness registers minimal stand-in modules for those imports and then loads
+/root/reference/phylopackage/bin/phyloligo.py with importlib, so that the functions below
+are the reference's code, executed unmodified:
+
+    ref.compute_frequency, ref.cut_sequence_and_count_pattern, ref.count2freq,
+    ref.compute_distances_joblib (Eucl, JSD, BC), phylodist.Eucl/JSD/KL, numpy.savetxt.
+
+Only numbers (inputs and the reference's outputs) are stored.  The stand-in `Seq` class
+complements A/C/G/T/N in both cases and leaves every other symbol unchanged, so 'minus'
+and 'both' vectors for IUPAC letters are pinned only "modulo the stand-in" (they stay
+non-ACGT either way).  KT and SC vectors come from SciPy and are labelled `scipy_`.
+"""
+import importlib.util
+import io
+import os
+import sys
+import types
+
+import numpy as np
+
+REF_ROOT = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub(name, **attrs):
+    mod = types.ModuleType(name)
+    mod.__dict__.update(attrs)
+    sys.modules[name] = mod
+    return mod
+
+
+def load_reference():
+    import joblib
+
+    _stub("scoop", futures=types.SimpleNamespace(map=map))
+    _stub("h5py")
+    table = str.maketrans("ACGTacgtNn", "TGCAtgcaNn")
+
+    class Seq(str):
+        def reverse_complement(self):
+            return Seq(str(self).translate(table)[::-1])
+
+    bio = _stub("Bio")
+    bio.Seq = _stub("Bio.Seq", Seq=Seq)
+    bio.SeqIO = _stub("Bio.SeqIO")
+    bio.Cluster = _stub("Bio.Cluster")
+    import sklearn.externals as ext   # the real package; only its long-gone `joblib` submodule is stood in
+    ext.joblib = _stub("sklearn.externals.joblib", Parallel=joblib.Parallel, delayed=joblib.delayed,
+                       dump=joblib.dump, load=joblib.load)
+    sys.path.insert(0, REF_ROOT)
+    spec = importlib.util.spec_from_file_location(
+        "phyloligo_ref", os.path.join(REF_ROOT, "phylopackage/bin/phyloligo.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    return ref
+
+
+PATTERNS = ["1", "11", "1111", "11111", "1101", "10011", "110101", "11011011"]
+STRANDS = ["both", "plus", "minus"]
+
+
+def build_contigs():
+    """Hand-built edge cases + seeded random contigs (lengths 0..5000, N runs, lower case, IUPAC)."""
+    rng = np.random.default_rng(20261003)
+    hand = [
+        "", "A", "AC", "ACG", "ACGT", "ACGTC", "ACNGT", "NNNNNNNN", "acgtn", "ACGTACGTACGTACGTACGTACGT",
+        "CCCCCCCCCCCC", "TTTTTTTTTTTTTTTT", "ACGTNACGTNNACGTTGCA", "acgtACGTacgtRYKMacgtSWBDHVNacgt",
+        "ACGT-ACGT*ACGT.ACGT1234ACGT", "GATTACAGATTACAGATTACA", "NACGTACGTACGTN", "ACGTACGNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNACGTTTGA",
+        "TGCATGCATGCATGCATGCATGCAUUUUTGCATGCA".replace("U", "X"), "CGCGCGCGCGCGCGCGCGCGCGCGCGCGCGCG",
+        "AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAC", "ACGTAC", "ACGTACG", "ACGTACGT", "ACGTACGTA", "nnnnACGTACGTnnnn",
+    ]
+    out = list(hand)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for length in [5, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 255, 256, 257, 500,
+                   777, 1000, 1023, 1024, 1025, 2000, 2048, 3000, 4096, 5000]:
+        s = alpha[rng.integers(0, 4, size=length)].copy()
+        out.append(s.tobytes().decode())
+    for length in [50, 200, 800, 2000, 3500]:           # N runs + lower case + IUPAC sprinkled in
+        s = alpha[rng.integers(0, 4, size=length)].copy()
+        for _ in range(max(1, length // 100)):
+            p = int(rng.integers(0, length))
+            q = min(length, p + int(rng.integers(1, 12)))
+            s[p:q] = ord("N")
+        for _ in range(max(1, length // 50)):
+            s[int(rng.integers(0, length))] = int(rng.choice(np.frombuffer(b"RYKMSWBDHVn", dtype=np.uint8)))
+        low = rng.random(length) < 0.3
+        s[low] = np.char.lower(s[low].view("S1")).view(np.uint8)
+        out.append(s.tobytes().decode())
+    skew = np.frombuffer(b"AAAACGTT", dtype=np.uint8)      # compositionally different contigs
+    for length in [600, 1500, 2500]:
+        out.append(skew[rng.integers(0, 8, size=length)].tobytes().decode())
+    return out
+
+
+def main():
+    ref = load_reference()
+    from phylopackage import phylodist  # the reference's metric library, via sys.path above
+
+    contigs = build_contigs()
+    store = {"contigs": np.array([c.encode() for c in contigs], dtype="S")}
+
+    # (1) profiles: the reference's Counter -> dense vector, for every pattern x strand
+    for pat in PATTERNS:
+        k = pat.count("1")
+        words = ["".join(w) for w in ref.product(("C", "G", "A", "T"), repeat=k)]
+        for strand in STRANDS:
+            counts = np.zeros((len(contigs), 4 ** k), dtype=np.int64)
+            totals = np.zeros(len(contigs), dtype=np.int64)
+            freqs = np.zeros((len(contigs), 4 ** k), dtype=np.float64)
+            for i, s in enumerate(contigs):
+                strand_seq = ref.select_strand(s, strand).upper()
+                cw, tot = ref.cut_sequence_and_count_pattern(strand_seq, pat)
+                counts[i] = [cw.get(w, 0) for w in words]
+                totals[i] = tot
+                freqs[i] = ref.compute_frequency(s, pat, strand)
+            store["counts_%s_%s" % (pat, strand)] = counts
+            store["totals_%s_%s" % (pat, strand)] = totals
+            store["freq_%s_%s" % (pat, strand)] = freqs
+    np.savez_compressed(os.path.join(HERE, "profiles.npz"), **store)
+
+    # (2) distance matrices of a 48-contig set through the reference's joblib driver
+    rng = np.random.default_rng(48)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    set48 = [alpha[rng.integers(0, 4, size=int(rng.integers(300, 2500)))].tobytes().decode() for _ in range(44)]
+    set48 += [set48[3], "", "NNNNNNNN", set48[10][:900]]      # a duplicate, two empty profiles, a prefix
+    dist = {"contigs": np.array([c.encode() for c in set48], dtype="S")}
+    for pat, strand in [("1111", "both"), ("11", "plus"), ("1101", "minus"), ("11011011", "both")]:
+        freq = np.vstack([ref.compute_frequency(s, pat, strand) for s in set48])
+        key = "%s_%s" % (pat, strand)
+        dist["freq_" + key] = freq
+        for metric in ("Eucl", "JSD", "BC"):
+            m = ref.compute_distances_joblib(freq, metric=metric, n_jobs=1)
+            dist["%s_%s" % (metric, key)] = m
+        if pat == "1111":
+            buf = io.BytesIO()
+            np.savetxt(buf, dist["JSD_" + key], delimiter="\t")
+            dist["matbytes_JSD_" + key] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
+            # per-pair functions called directly (phylodist.py), first 8 rows
+            sub = freq[:8]
+            dist["pair_Eucl_" + key] = np.array([[phylodist.Eucl(a, b) for b in sub] for a in sub])
+            dist["pair_JSD_" + key] = np.array([[phylodist.JSD(a, b) for b in sub] for a in sub])
+            dist["pair_KL_" + key] = np.array([[phylodist.KL(a, b) for b in sub] for a in sub])
+        # SciPy-pinned vectors for the two metrics the reference cannot run here
+        from scipy.stats import kendalltau, spearmanr
+        n = 16 if pat != "11011011" else 6
+        kt = np.zeros((n, n))
+        sc = np.zeros((n, n))
+        with np.errstate(all="ignore"):
+            for i in range(n):
+                for j in range(n):
+                    kt[i, j] = kendalltau(freq[i], freq[j], variant="b").statistic
+                    sc[i, j] = 1.0 - spearmanr(freq[i], freq[j]).correlation
+        dist["scipy_KT_" + key] = kt
+        dist["scipy_SC_" + key] = sc
+    np.savez_compressed(os.path.join(HERE, "distances.npz"), **dist)
+
+    # (3) C1 synthetic set (seed 1001, 1000 x 2 kb): hash of the counts + 16x16 corners
+    rng = np.random.default_rng(1001)
+    c1 = [alpha[rng.integers(0, 4, size=2000, dtype=np.uint8)].tobytes().decode() for _ in range(1000)]
+    freq = np.vstack([ref.compute_frequency(s, "1111", "both") for s in c1])
+    c1store = {"freq_first16": freq[:16], "freq_colsum": freq.sum(axis=0), "freq_rowsum": freq.sum(axis=1)}
+    for metric in ("Eucl", "JSD", "BC"):
+        c1store["corner_" + metric] = ref.compute_distances_joblib(freq[:16], metric=metric, n_jobs=1)
+        c1store["far_" + metric] = np.array([[ref.compute_distances_joblib(
+            np.vstack([freq[i], freq[j]]), metric=metric, n_jobs=1)[0, 1] for j in (500, 777, 999)] for i in (0, 1, 2)])
+    np.savez_compressed(os.path.join(HERE, "c1_synthetic.npz"), **c1store)
+
+    # (4) CLI resolution of -k / -p (phyloligo.py:1000-1041)
+    cli = {}
+    for name, argv in {
+        "default": ["-i", "x.fa", "--method", "joblib"],
+        "k6": ["-i", "x.fa", "--method", "joblib", "-k", "6"],
+        "p": ["-i", "x.fa", "--method", "joblib", "-p", "11011"],
+        "k_then_p": ["-i", "x.fa", "--method", "joblib", "-k", "5", "-p", "101"],
+        "p_then_k": ["-i", "x.fa", "--method", "joblib", "-p", "101", "-k", "5"],
+    }.items():
+        old = sys.argv
+        sys.argv = ["phyloligo.py"] + argv
+        try:
+            params = ref.get_cmd()
+        finally:
+            sys.argv = old
+        pat = params.pattern
+        if type(pat) == int:
+            pat = "1" * pat
+        cli[name] = np.array([" ".join(argv), str(pat), params.strand, params.dist, params.out_file, params.large,
+                              str(params.threads_max)], dtype="U")
+    np.savez_compressed(os.path.join(HERE, "cli.npz"), **cli)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
