@@ -1,0 +1,167 @@
+/*
+ * phyloligo_amd.h -- C ABI of the MI355X-native PhylOligo all-by-all contig distance path.
+ *
+ * The reference (itsmeludo/PhylOligo) is pure Python and has no FFI of its own; its seam for
+ * this path is two dispatcher functions keyed by the `--method` string plus a metric-name
+ * registry (paths relative to /root/reference/phylopackage/):
+ *
+ *   compute_frequencies(mthdrun, large, genome, pattern, strand, ...)   bin/phyloligo.py:980-997
+ *   compute_distances(mthdrun, large, frequencies, ..., dist, ...)      bin/phyloligo.py:536-553
+ *   call_dist = {"Eucl","JSD","KT","BC","SC"}                           bin/phyloligo.py:381
+ *   numpy.savetxt(out_file, res, delimiter="\t")                        bin/phyloligo.py:1059-1066
+ *
+ * Each entry point below names the reference function(s) it replaces.  The binding a
+ * PhylOligo maintainer would add (a ctypes stub selected by `--method hip`) is shown in
+ * INTEGRATION.md.  Plain pointers and sizes only; no torch / numpy types cross this line.
+ *
+ * Conventions
+ *   - every function returns PO_OK (0) or a negative po_status; po_last_error() gives the
+ *     message of the calling thread's last failure;
+ *   - `*_dev` entry points take DEVICE pointers and enqueue on the context's stream without
+ *     synchronising (the caller owns the stream: po_ctx_set_stream / po_ctx_synchronize);
+ *     the un-suffixed forms take HOST pointers, copy in, run the same kernels, copy out and
+ *     return when the result is in the caller's buffer;
+ *   - a profile is an exact integer count vector in the reference's word order
+ *     (itertools.product("CGAT", repeat=k), bin/phyloligo.py:653: C=0,G=1,A=2,T=3, first
+ *     letter most significant) plus the number of counted words of the record;
+ *   - there is NO CPU fallback: without a HIP device every compute call fails with PO_ENODEV.
+ */
+#ifndef PHYLOLIGO_AMD_H
+#define PHYLOLIGO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PO_ABI_VERSION 1
+
+typedef struct po_ctx po_ctx;
+
+typedef enum po_status {
+    PO_OK = 0,
+    PO_EINVAL = -1,       /* bad argument (unknown strand / metric / pattern, null pointer, bad range) */
+    PO_ENODEV = -2,       /* no usable HIP device */
+    PO_ENOMEM = -3,       /* host or device allocation failed */
+    PO_EHIP = -4,         /* a HIP runtime call or kernel launch failed */
+    PO_EUNSUPPORTED = -5, /* valid request outside the implemented envelope (window > 32, k > 8) */
+    PO_EIO = -6,          /* file could not be opened / written, malformed FASTA */
+} po_status;
+
+/* -s/--strand choices, bin/phyloligo.py:1010 and select_strand :124-149 */
+typedef enum po_strand { PO_STRAND_BOTH = 0, PO_STRAND_PLUS = 1, PO_STRAND_MINUS = 2 } po_strand;
+
+/* -d/--distance choices, bin/phyloligo.py:1012; functions in core/phylodist.py:36-85 */
+typedef enum po_metric { PO_EUCL = 0, PO_JSD = 1, PO_KT = 2, PO_BC = 3, PO_SC = 4 } po_metric;
+
+/* element type of the distance matrix: float64 is what compute_distances_joblib returns
+ * (bin/phyloligo.py:364-392); float32 is the container type of the --large memmap variant
+ * (bin/phyloligo.py:413) -- values are computed in float64 and rounded once on store. */
+typedef enum po_dtype { PO_F64 = 0, PO_F32 = 1 } po_dtype;
+
+/* flags of po_pairwise* */
+#define PO_FLAG_NO_SYMMETRY 1u /* compute every (i,j) independently even for the full matrix
+                                  (what sklearn does for n_jobs>1); default mirrors j<i from i<j */
+
+/* Filled by po_pairwise* when non-NULL.  Times are HIP-event times on the context's stream;
+ * asking for them makes the call synchronise. */
+typedef struct po_stats {
+    double prep_ms;        /* counts -> device working layout (+ per-row terms)                  */
+    double kernel_ms;      /* the tile kernel(s) of the metric                                    */
+    double total_ms;       /* prep + kernel + anything between                                    */
+    uint64_t pairs;        /* matrix entries written / 2 (unordered pairs incl. half the diagonal) */
+    uint64_t tiles;        /* workgroup tiles launched                                            */
+    uint32_t kernel_id;    /* which tile kernel ran (PO_KERNEL_*)                                 */
+    uint32_t reserved;
+} po_stats;
+
+#define PO_KERNEL_VALU_JSD 1u
+#define PO_KERNEL_VALU_BC 2u
+#define PO_KERNEL_MFMA_F64_GRAM 3u
+#define PO_KERNEL_MFMA_I8_GRAM 4u
+#define PO_KERNEL_VALU_KT 5u
+
+/* ---- library / context ------------------------------------------------------------------ */
+const char* po_version(void);
+int po_abi_version(void);
+const char* po_last_error(void);
+const char* po_status_string(int status);
+int po_device_count(void);                              /* 0 when no HIP device is visible      */
+int po_ctx_create(po_ctx** out, int device_id);         /* one context per GPU / per process rank */
+void po_ctx_destroy(po_ctx* ctx);
+int po_ctx_set_stream(po_ctx* ctx, void* hip_stream);   /* hipStream_t of the caller; NULL = default */
+int po_ctx_synchronize(po_ctx* ctx);
+int po_ctx_device_name(po_ctx* ctx, char* buf, size_t len);
+
+/* ---- pattern ---------------------------------------------------------------------------- *
+ * `pattern` is the -p string of '1'/'0' (bin/phyloligo.py:1027); -k N is "1"*N (:1040-1041).
+ * window = len(pattern) <= 32, k = number of '1' <= 8, dim = 4^k.                            */
+int po_pattern_info(const char* pattern, uint32_t* window, uint32_t* k, uint64_t* dim);
+
+/* ---- stage 1: profiles ------------------------------------------------------------------ *
+ * Replaces compute_frequencies_joblib (bin/phyloligo.py:847-877), i.e. per record
+ * select_strand (:124-149) -> upper() (:683) -> cut_sequence_and_count_pattern (:601-631) ->
+ * the dense C,G,A,T ordering of count2freq (:653); the division count/total of :656 is left
+ * to the consumer (po_frequencies*, po_pairwise*) so that the canonical result is exact.
+ *   seq      concatenated sequence bytes of all records, in file order, line ends / blanks
+ *            already removed, case preserved (any byte that is not ACGTacgt separates words)
+ *   offsets  n_seqs+1 byte offsets into seq (offsets[0]=0, non-decreasing)
+ *   counts   [n_seqs][dim] uint32, row major          totals  [n_seqs] uint64                 */
+int po_count_profiles(po_ctx* ctx, const uint8_t* seq, const uint64_t* offsets, uint64_t n_seqs,
+                      const char* pattern, int strand, uint32_t* counts, uint64_t* totals);
+int po_count_profiles_dev(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets, uint64_t n_seqs,
+                          uint64_t total_bytes, const char* pattern, int strand,
+                          uint32_t* d_counts, uint64_t* d_totals);
+
+/* count2freq (bin/phyloligo.py:633-661): freq[i][w] = counts[i][w] / totals[i] in float64
+ * (0 for an empty record); this is the matrix -q/--outfreq writes (:1059-1061).               */
+int po_frequencies(po_ctx* ctx, const uint32_t* counts, const uint64_t* totals, uint64_t n, uint32_t dim,
+                   double* freq);
+int po_frequencies_dev(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
+                       uint32_t dim, double* d_freq);
+
+/* ---- stage 2: pairwise matrix ----------------------------------------------------------- *
+ * Replaces compute_distances_joblib (bin/phyloligo.py:364-392) = sklearn pairwise_distances
+ * over phylodist.Eucl / JSD / KT / SC (core/phylodist.py:36-85) and SciPy 'braycurtis'.
+ * Computes rows [row_begin,row_end) x all n columns:
+ *     out[(i-row_begin)*ld_out + j]   0 <= j < n,   ld_out >= n  (elements, not bytes)
+ * Diagonal as the reference produces it: Eucl/JSD/BC/SC 0, KT 1 (0 for a constant row).
+ * Row blocks are independent, which is how the matrix shards over GPUs (one context each).   */
+int po_pairwise(po_ctx* ctx, const uint32_t* counts, const uint64_t* totals, uint64_t n, uint32_t dim,
+                int metric, uint64_t row_begin, uint64_t row_end, int out_dtype, void* out, uint64_t ld_out,
+                uint32_t flags, po_stats* stats);
+int po_pairwise_dev(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                    int metric, uint64_t row_begin, uint64_t row_end, int out_dtype, void* d_out,
+                    uint64_t ld_out, uint32_t flags, po_stats* stats);
+
+/* The same from a float64 frequency matrix freq[n][dim] (row major) -- literally the
+ * `frequencies` argument of compute_distances / compute_distances_joblib
+ * (bin/phyloligo.py:536-553, :364-392), for callers that hold frequencies rather than counts. */
+int po_pairwise_freq(po_ctx* ctx, const double* freq, uint64_t n, uint32_t dim, int metric, uint64_t row_begin,
+                     uint64_t row_end, int out_dtype, void* out, uint64_t ld_out, uint32_t flags, po_stats* stats);
+int po_pairwise_freq_dev(po_ctx* ctx, const double* d_freq, uint64_t n, uint32_t dim, int metric,
+                         uint64_t row_begin, uint64_t row_end, int out_dtype, void* d_out, uint64_t ld_out,
+                         uint32_t flags, po_stats* stats);
+
+/* bytes of device workspace po_pairwise_dev will hold for this problem (allocated lazily on
+ * first use and kept by the context; call once before timing to keep hipMalloc out of it)    */
+int po_pairwise_reserve(po_ctx* ctx, uint64_t n, uint32_t dim, int metric);
+
+/* ---- host-side formats either side of the path ------------------------------------------ *
+ * FASTA ingest with the semantics of Bio.SeqIO.parse(genome, "fasta") as used at
+ * bin/phyloligo.py:869: '>' at line start opens a record, sequence lines are right-stripped
+ * and joined, ' ' and '\r' removed.  Two calls: sizes first, then fill.                      */
+int po_fasta_scan(const uint8_t* data, uint64_t len, uint64_t* n_records, uint64_t* seq_bytes);
+int po_fasta_extract(const uint8_t* data, uint64_t len, uint8_t* seq_out, uint64_t* offsets_out,
+                     uint64_t* title_begin, uint64_t* title_end);
+
+/* numpy.savetxt(path, m, delimiter="\t") of bin/phyloligo.py:1061,1066: "%.18e" values, '\t'
+ * between columns, '\n' after each row, "nan"/"inf" spelled as numpy spells them.            */
+int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, uint64_t ld, const char* path, int append);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHYLOLIGO_AMD_H */

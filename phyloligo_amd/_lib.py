@@ -1,0 +1,97 @@
+"""ctypes binding of libphyloligo_amd.so (include/phyloligo_amd.h).
+
+The shared library is the product: there is no Python or CPU fallback.  If it has not been
+built (`python -c "import __graft_entry__ as g; g.build()"` or `make -C phyloligo_amd/csrc`)
+importing this module raises, and every compute call fails with PO_ENODEV when no HIP device
+is visible.
+"""
+import ctypes
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphyloligo_amd.so")
+
+PO_OK, PO_EINVAL, PO_ENODEV, PO_ENOMEM, PO_EHIP, PO_EUNSUPPORTED, PO_EIO = 0, -1, -2, -3, -4, -5, -6
+STRANDS = {"both": 0, "plus": 1, "minus": 2}
+METRICS = {"Eucl": 0, "JSD": 1, "KT": 2, "BC": 3, "SC": 4}
+PO_F64, PO_F32 = 0, 1
+PO_FLAG_NO_SYMMETRY = 1
+
+
+class PoStats(ctypes.Structure):
+    _fields_ = [("prep_ms", ctypes.c_double), ("kernel_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
+                ("pairs", ctypes.c_uint64), ("tiles", ctypes.c_uint64), ("kernel_id", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
+
+
+class PhyloligoError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("phyloligo_amd: %s (status %d)" % (message, status))
+        self.status = status
+
+
+_c = ctypes
+_vp, _u64, _u32, _int, _cp = _c.c_void_p, _c.c_uint64, _c.c_uint32, _c.c_int, _c.c_char_p
+
+# name -> (restype, argtypes); every symbol include/phyloligo_amd.h declares
+SIGNATURES = {
+    "po_version": (_cp, []),
+    "po_abi_version": (_int, []),
+    "po_last_error": (_cp, []),
+    "po_status_string": (_cp, [_int]),
+    "po_device_count": (_int, []),
+    "po_ctx_create": (_int, [_c.POINTER(_vp), _int]),
+    "po_ctx_destroy": (None, [_vp]),
+    "po_ctx_set_stream": (_int, [_vp, _vp]),
+    "po_ctx_synchronize": (_int, [_vp]),
+    "po_ctx_device_name": (_int, [_vp, _c.c_char_p, _c.c_size_t]),
+    "po_pattern_info": (_int, [_cp, _c.POINTER(_u32), _c.POINTER(_u32), _c.POINTER(_u64)]),
+    "po_count_profiles": (_int, [_vp, _vp, _vp, _u64, _cp, _int, _vp, _vp]),
+    "po_count_profiles_dev": (_int, [_vp, _vp, _vp, _u64, _u64, _cp, _int, _vp, _vp]),
+    "po_frequencies": (_int, [_vp, _vp, _vp, _u64, _u32, _vp]),
+    "po_frequencies_dev": (_int, [_vp, _vp, _vp, _u64, _u32, _vp]),
+    "po_pairwise": (_int, [_vp, _vp, _vp, _u64, _u32, _int, _u64, _u64, _int, _vp, _u64, _u32, _c.POINTER(PoStats)]),
+    "po_pairwise_dev": (_int, [_vp, _vp, _vp, _u64, _u32, _int, _u64, _u64, _int, _vp, _u64, _u32, _c.POINTER(PoStats)]),
+    "po_pairwise_freq": (_int, [_vp, _vp, _u64, _u32, _int, _u64, _u64, _int, _vp, _u64, _u32, _c.POINTER(PoStats)]),
+    "po_pairwise_freq_dev": (_int, [_vp, _vp, _u64, _u32, _int, _u64, _u64, _int, _vp, _u64, _u32, _c.POINTER(PoStats)]),
+    "po_pairwise_reserve": (_int, [_vp, _u64, _u32, _int]),
+    "po_fasta_scan": (_int, [_vp, _u64, _c.POINTER(_u64), _c.POINTER(_u64)]),
+    "po_fasta_extract": (_int, [_vp, _u64, _vp, _vp, _vp, _vp]),
+    "po_write_mat_text": (_int, [_vp, _u64, _u64, _u64, _cp, _int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once.  torch (when installed) is imported first: it bundles its own
+    libamdhip64.so.7, and a process must hold exactly one HIP runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "phyloligo_amd: %s is missing -- build it (make -C phyloligo_amd/csrc, needs hipcc). "
+            "There is no CPU fallback." % LIB_PATH)
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header and library out of step
+        fn.restype = res
+        fn.argtypes = args
+    if lib.po_abi_version() != 1:
+        raise ImportError("phyloligo_amd: ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != PO_OK:
+        lib = load()
+        msg = lib.po_last_error().decode("utf-8", "replace") or lib.po_status_string(status).decode()
+        raise PhyloligoError(status, msg)

@@ -1,0 +1,208 @@
+"""Thin Python face of the C ABI: numpy arrays (host entry points) or torch CUDA tensors
+(device entry points) in, the same out.  All arithmetic happens in libphyloligo_amd.so.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import METRICS, STRANDS, PO_F32, PO_F64, PO_FLAG_NO_SYMMETRY, PoStats, check
+
+
+def normalise_pattern(pattern):
+    """-k N and -p PATTERN share one destination in the reference CLI
+    (bin/phyloligo.py:1006,1027); an int means the contiguous pattern "1"*N (:1040-1041)."""
+    if isinstance(pattern, (int, np.integer)) and not isinstance(pattern, bool):
+        pattern = "1" * int(pattern)
+    return str(pattern)
+
+
+def pattern_info(pattern):
+    lib = _lib.load()
+    w, k, d = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+    check(lib.po_pattern_info(normalise_pattern(pattern).encode(), ctypes.byref(w), ctypes.byref(k), ctypes.byref(d)))
+    return w.value, k.value, d.value
+
+
+def device_count():
+    return _lib.load().po_device_count()
+
+
+def _np_ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Context:
+    """One po_ctx = one GPU.  Device-tensor calls run on torch's current stream."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        self.device = int(device)
+        check(self._lib.po_ctx_create(ctypes.byref(self._h), self.device))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.po_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        check(self._lib.po_ctx_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def synchronize(self):
+        check(self._lib.po_ctx_synchronize(self._h))
+
+    def _use_torch_stream(self):
+        import torch
+        check(self._lib.po_ctx_set_stream(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    # ---- stage 1 ---------------------------------------------------------------------------
+    def count_profiles(self, seq, offsets, pattern="1111", strand="both"):
+        """seq: uint8 concatenated sequence bytes, offsets: uint64[n+1].  numpy in -> numpy out
+        (uint32 counts[n, 4^k], uint64 totals[n]); torch CUDA tensors in -> torch CUDA tensors out."""
+        pat = normalise_pattern(pattern)
+        _, _, dim = pattern_info(pat)
+        if strand not in STRANDS:
+            raise _lib.PhyloligoError(_lib.PO_EINVAL, "strand must be one of both/plus/minus (got %r)" % (strand,))
+        if _is_torch(seq):
+            import torch
+            n = offsets.numel() - 1
+            assert seq.dtype == torch.uint8 and seq.is_cuda and seq.is_contiguous()
+            assert offsets.dtype == torch.int64 and offsets.is_cuda and offsets.is_contiguous()
+            counts = torch.empty((n, dim), dtype=torch.int32, device=seq.device)
+            totals = torch.empty((n,), dtype=torch.int64, device=seq.device)
+            self._use_torch_stream()
+            check(self._lib.po_count_profiles_dev(self._h, seq.data_ptr(), offsets.data_ptr(), n, seq.numel(),
+                                                  pat.encode(), STRANDS[strand], counts.data_ptr(), totals.data_ptr()))
+            return counts, totals
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.shape[0] - 1
+        counts = np.zeros((n, dim), dtype=np.uint32)
+        totals = np.zeros((n,), dtype=np.uint64)
+        check(self._lib.po_count_profiles(self._h, _np_ptr(seq), _np_ptr(offsets), n, pat.encode(), STRANDS[strand],
+                                          _np_ptr(counts), _np_ptr(totals)))
+        return counts, totals
+
+    def frequencies(self, counts, totals):
+        if _is_torch(counts):
+            import torch
+            n, dim = counts.shape
+            out = torch.empty((n, dim), dtype=torch.float64, device=counts.device)
+            self._use_torch_stream()
+            check(self._lib.po_frequencies_dev(self._h, counts.data_ptr(), totals.data_ptr(), n, dim, out.data_ptr()))
+            return out
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        totals = np.ascontiguousarray(totals, dtype=np.uint64)
+        n, dim = counts.shape
+        out = np.zeros((n, dim), dtype=np.float64)
+        check(self._lib.po_frequencies(self._h, _np_ptr(counts), _np_ptr(totals), n, dim, _np_ptr(out)))
+        return out
+
+    # ---- stage 2 ---------------------------------------------------------------------------
+    def reserve(self, n, dim, metric):
+        check(self._lib.po_pairwise_reserve(self._h, n, dim, METRICS[metric]))
+
+    def pairwise(self, counts, totals, metric="Eucl", row_begin=0, row_end=None, dtype="float64", symmetric=True,
+                 out=None, want_stats=False):
+        """Rows [row_begin,row_end) x all columns of the distance matrix from integer profiles."""
+        return self._pairwise(counts, totals, None, metric, row_begin, row_end, dtype, symmetric, out, want_stats)
+
+    def pairwise_freq(self, freq, metric="Eucl", row_begin=0, row_end=None, dtype="float64", symmetric=True,
+                      out=None, want_stats=False):
+        """The same from a float64 frequency matrix (the reference's `frequencies` argument)."""
+        return self._pairwise(None, None, freq, metric, row_begin, row_end, dtype, symmetric, out, want_stats)
+
+    def _pairwise(self, counts, totals, freq, metric, row_begin, row_end, dtype, symmetric, out, want_stats):
+        if metric not in METRICS:
+            raise _lib.PhyloligoError(_lib.PO_EINVAL, "unknown metric %r" % (metric,))
+        src = freq if freq is not None else counts
+        n, dim = src.shape
+        row_end = n if row_end is None else row_end
+        rows = max(0, row_end - row_begin)
+        f32 = str(dtype) in ("float32", "torch.float32", "f32")
+        code = PO_F32 if f32 else PO_F64
+        flags = 0 if symmetric else PO_FLAG_NO_SYMMETRY
+        stats = PoStats()
+        sp = ctypes.byref(stats) if want_stats else None
+        if _is_torch(src):
+            import torch
+            if out is None:
+                out = torch.empty((rows, n), dtype=torch.float32 if f32 else torch.float64, device=src.device)
+            ld = out.stride(0) if rows > 1 else max(n, out.stride(0) if out.dim() == 2 else n)
+            self._use_torch_stream()
+            if freq is not None:
+                assert freq.dtype == torch.float64 and freq.is_contiguous()
+                check(self._lib.po_pairwise_freq_dev(self._h, freq.data_ptr(), n, dim, METRICS[metric], row_begin,
+                                                     row_end, code, out.data_ptr(), ld, flags, sp))
+            else:
+                assert counts.dtype == torch.int32 and totals.dtype == torch.int64
+                assert counts.is_contiguous() and totals.is_contiguous()
+                check(self._lib.po_pairwise_dev(self._h, counts.data_ptr(), totals.data_ptr(), n, dim, METRICS[metric],
+                                                row_begin, row_end, code, out.data_ptr(), ld, flags, sp))
+        else:
+            if out is None:
+                out = np.zeros((rows, n), dtype=np.float32 if f32 else np.float64)
+            ld = out.strides[0] // out.itemsize if rows > 0 and n > 0 else n
+            if freq is not None:
+                freq = np.ascontiguousarray(freq, dtype=np.float64)
+                check(self._lib.po_pairwise_freq(self._h, _np_ptr(freq), n, dim, METRICS[metric], row_begin, row_end,
+                                                 code, _np_ptr(out), max(ld, n), flags, sp))
+            else:
+                counts = np.ascontiguousarray(counts, dtype=np.uint32)
+                totals = np.ascontiguousarray(totals, dtype=np.uint64)
+                check(self._lib.po_pairwise(self._h, _np_ptr(counts), _np_ptr(totals), n, dim, METRICS[metric],
+                                            row_begin, row_end, code, _np_ptr(out), max(ld, n), flags, sp))
+        if want_stats:
+            return out, {"prep_ms": stats.prep_ms, "kernel_ms": stats.kernel_ms, "total_ms": stats.total_ms,
+                         "pairs": stats.pairs, "tiles": stats.tiles, "kernel_id": stats.kernel_id}
+        return out
+
+
+# ---- host formats -------------------------------------------------------------------------------
+def fasta_index(data):
+    """bytes / numpy uint8 of a FASTA file -> (seq uint8[total], offsets uint64[n+1], titles list)."""
+    lib = _lib.load()
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    buf = np.ascontiguousarray(buf)
+    nrec, nbytes = ctypes.c_uint64(), ctypes.c_uint64()
+    check(lib.po_fasta_scan(_np_ptr(buf), buf.shape[0], ctypes.byref(nrec), ctypes.byref(nbytes)))
+    seq = np.zeros(nbytes.value, dtype=np.uint8)
+    offsets = np.zeros(nrec.value + 1, dtype=np.uint64)
+    tb = np.zeros(nrec.value, dtype=np.uint64)
+    te = np.zeros(nrec.value, dtype=np.uint64)
+    check(lib.po_fasta_extract(_np_ptr(buf), buf.shape[0], _np_ptr(seq), _np_ptr(offsets), _np_ptr(tb), _np_ptr(te)))
+    raw = buf.tobytes() if nrec.value < 100000 else None
+    titles = None
+    if raw is not None:
+        titles = [raw[int(b):int(e)].decode("latin-1") for b, e in zip(tb, te)]
+    return seq, offsets, titles
+
+
+def write_mat_text(path, m, append=False):
+    """numpy.savetxt(path, m, delimiter="\\t") byte for byte (bin/phyloligo.py:1061,1066)."""
+    lib = _lib.load()
+    m = np.ascontiguousarray(m, dtype=np.float64)
+    if m.ndim == 1:
+        m = m.reshape(-1, 1)      # savetxt writes a 1-D array one value per line
+    rows, cols = m.shape
+    check(lib.po_write_mat_text(_np_ptr(m), rows, cols, cols, str(path).encode(), 1 if append else 0))

@@ -1,0 +1,461 @@
+// C ABI of libphyloligo_amd.so (include/phyloligo_amd.h): contexts, argument checking, the
+// host-pointer convenience forms, and the dispatch of a pairwise request onto the tile kernels.
+#include "po_internal.h"
+
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <new>
+
+// ---- errors --------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void po_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* po_last_error(void) { return g_err; }
+
+extern "C" const char* po_status_string(int status) {
+    switch (status) {
+        case PO_OK: return "ok";
+        case PO_EINVAL: return "invalid argument";
+        case PO_ENODEV: return "no usable HIP device";
+        case PO_ENOMEM: return "out of memory";
+        case PO_EHIP: return "HIP runtime error";
+        case PO_EUNSUPPORTED: return "unsupported request";
+        case PO_EIO: return "I/O error";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char* po_version(void) { return "phyloligo_amd 0.1 (gfx950)"; }
+extern "C" int po_abi_version(void) { return PO_ABI_VERSION; }
+
+extern "C" int po_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// ---- context -------------------------------------------------------------------------------
+extern "C" int po_ctx_create(po_ctx** out, int device_id) {
+    PO_REQUIRE(out != nullptr, "po_ctx_create: out is NULL");
+    *out = nullptr;
+    const int n = po_device_count();
+    if (n <= 0) {
+        po_set_error("po_ctx_create: no HIP device visible (this library has no CPU fallback)");
+        return PO_ENODEV;
+    }
+    PO_REQUIRE(device_id >= 0 && device_id < n, "po_ctx_create: device %d out of range (0..%d)", device_id, n - 1);
+    po_ctx* c = new (std::nothrow) po_ctx();
+    if (!c) { po_set_error("po_ctx_create: host allocation failed"); return PO_ENOMEM; }
+    c->device = device_id;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&c->prop, device_id);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) {
+        po_set_error("po_ctx_create: %s", hipGetErrorString(e));
+        delete c;
+        return PO_EHIP;
+    }
+    *out = c;
+    return PO_OK;
+}
+
+static void buf_free(po_buf* b) {
+    if (b->p) (void)hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+}
+
+extern "C" void po_ctx_destroy(po_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    buf_free(&ctx->ws_freq);
+    buf_free(&ctx->ws_rowstat);
+    buf_free(&ctx->ws_aux);
+    buf_free(&ctx->ws_io);
+    buf_free(&ctx->ws_logtab);
+    for (int i = 0; i < 4; ++i)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    delete ctx;
+}
+
+extern "C" int po_ctx_set_stream(po_ctx* ctx, void* hip_stream) {
+    PO_REQUIRE(ctx != nullptr, "po_ctx_set_stream: ctx is NULL");
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return PO_OK;
+}
+
+extern "C" int po_ctx_synchronize(po_ctx* ctx) {
+    PO_REQUIRE(ctx != nullptr, "po_ctx_synchronize: ctx is NULL");
+    PO_HIP(hipSetDevice(ctx->device));
+    PO_HIP(hipStreamSynchronize(ctx->stream));
+    return PO_OK;
+}
+
+extern "C" int po_ctx_device_name(po_ctx* ctx, char* buf, size_t len) {
+    PO_REQUIRE(ctx != nullptr && buf != nullptr && len > 0, "po_ctx_device_name: bad argument");
+    snprintf(buf, len, "%s (%s, %d CUs)", ctx->prop.name, ctx->prop.gcnArchName, ctx->prop.multiProcessorCount);
+    return PO_OK;
+}
+
+int po_buf_reserve(po_ctx* ctx, po_buf* b, size_t bytes) {
+    if (bytes <= b->cap) return PO_OK;
+    // growing is rare (first call for a problem size): finish queued work that may still use the old block
+    PO_HIP(hipStreamSynchronize(ctx->stream));
+    buf_free(b);
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b->p, want);
+    if (e != hipSuccess) {
+        b->p = nullptr;
+        po_set_error("device allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        return PO_ENOMEM;
+    }
+    b->cap = want;
+    return PO_OK;
+}
+
+// ---- pattern -------------------------------------------------------------------------------
+int po_pattern_compile(const char* pattern, po_pattern* out) {
+    PO_REQUIRE(pattern != nullptr && out != nullptr, "pattern is NULL");
+    memset(out, 0, sizeof(*out));
+    const size_t W = strlen(pattern);
+    PO_REQUIRE(W >= 1, "pattern is empty");
+    for (size_t i = 0; i < W; ++i)
+        PO_REQUIRE(pattern[i] == '0' || pattern[i] == '1', "pattern '%s' must contain only 0 and 1", pattern);
+    if (W > PO_MAX_WINDOW) { po_set_error("pattern longer than %d positions is not supported", PO_MAX_WINDOW); return PO_EUNSUPPORTED; }
+    uint32_t k = 0;
+    for (size_t i = 0; i < W; ++i)
+        if (pattern[i] == '1') out->ones[k++] = (uint32_t)i;     // k <= W <= PO_MAX_WINDOW
+    PO_REQUIRE(k >= 1, "pattern '%s' selects no position", pattern);
+    if (k > PO_MAX_K) { po_set_error("patterns with more than %d selected positions (4^k words) are not supported", PO_MAX_K); return PO_EUNSUPPORTED; }
+    out->window = (uint32_t)W;
+    out->k = k;
+    out->dim = 1u << (2 * k);
+    // runs of consecutive '1': window position x sits at bits [2(W-1-x), +2) of the rolling register
+    uint32_t rank = 0, nruns = 0;
+    for (size_t x = 0; x < W;) {
+        if (pattern[x] != '1') { ++x; continue; }
+        size_t y = x;
+        while (y < W && pattern[y] == '1') ++y;
+        const uint32_t len = (uint32_t)(y - x);
+        out->src_shift[nruns] = 2 * (uint32_t)(W - x - len);
+        out->dst_shift[nruns] = 2 * (k - rank - len);
+        out->mask[nruns] = (len >= 16) ? 0xFFFFFFFFu : ((1u << (2 * len)) - 1u);
+        ++nruns;
+        rank += len;
+        x = y;
+    }
+    out->nruns = nruns;
+    return PO_OK;
+}
+
+extern "C" int po_pattern_info(const char* pattern, uint32_t* window, uint32_t* k, uint64_t* dim) {
+    po_pattern p;
+    int rc = po_pattern_compile(pattern, &p);
+    if (rc) return rc;
+    if (window) *window = p.window;
+    if (k) *k = p.k;
+    if (dim) *dim = p.dim;
+    return PO_OK;
+}
+
+static int check_strand(int strand) {
+    // select_strand prints an error and exits(1) for anything else (phyloligo.py:146-148)
+    PO_REQUIRE(strand == PO_STRAND_BOTH || strand == PO_STRAND_PLUS || strand == PO_STRAND_MINUS,
+               "strand must be one of both/plus/minus (got %d)", strand);
+    return PO_OK;
+}
+
+static int check_metric(int metric) {
+    // compute_distances_joblib prints "unknown metric" and exits(1) (phyloligo.py:383-385)
+    PO_REQUIRE(metric >= PO_EUCL && metric <= PO_SC, "unknown metric %d (Eucl=0, JSD=1, KT=2, BC=3, SC=4)", metric);
+    return PO_OK;
+}
+
+// ---- stage 1 -------------------------------------------------------------------------------
+extern "C" int po_count_profiles_dev(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets, uint64_t n_seqs,
+                                     uint64_t total_bytes, const char* pattern, int strand, uint32_t* d_counts,
+                                     uint64_t* d_totals) {
+    PO_REQUIRE(ctx != nullptr, "po_count_profiles_dev: ctx is NULL");
+    po_pattern pat;
+    int rc = po_pattern_compile(pattern, &pat);
+    if (rc) return rc;
+    rc = check_strand(strand);
+    if (rc) return rc;
+    if (n_seqs == 0) return PO_OK;
+    PO_REQUIRE(d_offsets && d_counts && d_totals, "po_count_profiles_dev: NULL buffer");
+    PO_REQUIRE(d_seq != nullptr || total_bytes == 0, "po_count_profiles_dev: NULL sequence buffer");
+    PO_REQUIRE((reinterpret_cast<uintptr_t>(d_seq) & 15u) == 0, "po_count_profiles_dev: sequence buffer must be 16-byte aligned");
+    PO_HIP(hipSetDevice(ctx->device));
+    return po_launch_count(ctx, d_seq, d_offsets, n_seqs, total_bytes, pat, strand, d_counts, d_totals);
+}
+
+extern "C" int po_count_profiles(po_ctx* ctx, const uint8_t* seq, const uint64_t* offsets, uint64_t n_seqs,
+                                 const char* pattern, int strand, uint32_t* counts, uint64_t* totals) {
+    PO_REQUIRE(ctx != nullptr, "po_count_profiles: ctx is NULL");
+    po_pattern pat;
+    int rc = po_pattern_compile(pattern, &pat);
+    if (rc) return rc;
+    rc = check_strand(strand);
+    if (rc) return rc;
+    if (n_seqs == 0) return PO_OK;
+    PO_REQUIRE(offsets && counts && totals, "po_count_profiles: NULL buffer");
+    PO_REQUIRE(offsets[0] == 0, "po_count_profiles: offsets[0] must be 0");
+    for (uint64_t i = 0; i < n_seqs; ++i)
+        PO_REQUIRE(offsets[i + 1] >= offsets[i], "po_count_profiles: offsets must be non-decreasing (record %llu)", (unsigned long long)i);
+    const uint64_t total = offsets[n_seqs];
+    PO_REQUIRE(seq != nullptr || total == 0, "po_count_profiles: NULL sequence buffer");
+    PO_HIP(hipSetDevice(ctx->device));
+
+    const size_t b_seq = po_round_up(total + 64, 256);
+    const size_t b_off = po_round_up((n_seqs + 1) * sizeof(uint64_t), 256);
+    const size_t b_cnt = po_round_up(n_seqs * (uint64_t)pat.dim * sizeof(uint32_t), 256);
+    const size_t b_tot = po_round_up(n_seqs * sizeof(uint64_t), 256);
+    rc = po_buf_reserve(ctx, &ctx->ws_io, b_seq + b_off + b_cnt + b_tot);
+    if (rc) return rc;
+    uint8_t* base = static_cast<uint8_t*>(ctx->ws_io.p);
+    uint8_t* d_seq = base;
+    uint64_t* d_off = reinterpret_cast<uint64_t*>(base + b_seq);
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(base + b_seq + b_off);
+    uint64_t* d_tot = reinterpret_cast<uint64_t*>(base + b_seq + b_off + b_cnt);
+    if (total) PO_HIP(hipMemcpyAsync(d_seq, seq, total, hipMemcpyHostToDevice, ctx->stream));
+    PO_HIP(hipMemcpyAsync(d_off, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = po_launch_count(ctx, d_seq, d_off, n_seqs, total, pat, strand, d_cnt, d_tot);
+    if (rc) return rc;
+    PO_HIP(hipMemcpyAsync(counts, d_cnt, n_seqs * (uint64_t)pat.dim * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PO_HIP(hipMemcpyAsync(totals, d_tot, n_seqs * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PO_HIP(hipStreamSynchronize(ctx->stream));
+    return PO_OK;
+}
+
+extern "C" int po_frequencies_dev(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
+                                  uint32_t dim, double* d_freq) {
+    PO_REQUIRE(ctx != nullptr, "po_frequencies_dev: ctx is NULL");
+    if (n == 0) return PO_OK;
+    PO_REQUIRE(d_counts && d_totals && d_freq && dim > 0, "po_frequencies_dev: bad argument");
+    PO_HIP(hipSetDevice(ctx->device));
+    return po_launch_freq_rowmajor(ctx, d_counts, d_totals, n, dim, d_freq);
+}
+
+extern "C" int po_frequencies(po_ctx* ctx, const uint32_t* counts, const uint64_t* totals, uint64_t n, uint32_t dim,
+                              double* freq) {
+    PO_REQUIRE(ctx != nullptr, "po_frequencies: ctx is NULL");
+    if (n == 0) return PO_OK;
+    PO_REQUIRE(counts && totals && freq && dim > 0, "po_frequencies: bad argument");
+    PO_HIP(hipSetDevice(ctx->device));
+    const size_t b_cnt = po_round_up(n * (uint64_t)dim * sizeof(uint32_t), 256);
+    const size_t b_tot = po_round_up(n * sizeof(uint64_t), 256);
+    const size_t b_frq = n * (uint64_t)dim * sizeof(double);
+    int rc = po_buf_reserve(ctx, &ctx->ws_io, b_cnt + b_tot + b_frq);
+    if (rc) return rc;
+    uint8_t* base = static_cast<uint8_t*>(ctx->ws_io.p);
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(base);
+    uint64_t* d_tot = reinterpret_cast<uint64_t*>(base + b_cnt);
+    double* d_frq = reinterpret_cast<double*>(base + b_cnt + b_tot);
+    PO_HIP(hipMemcpyAsync(d_cnt, counts, n * (uint64_t)dim * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PO_HIP(hipMemcpyAsync(d_tot, totals, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = po_launch_freq_rowmajor(ctx, d_cnt, d_tot, n, dim, d_frq);
+    if (rc) return rc;
+    PO_HIP(hipMemcpyAsync(freq, d_frq, b_frq, hipMemcpyDeviceToHost, ctx->stream));
+    PO_HIP(hipStreamSynchronize(ctx->stream));
+    return PO_OK;
+}
+
+// ---- stage 2 -------------------------------------------------------------------------------
+static const uint64_t kPadRows = 128;   // tile edge of the VALU / Gram kernels
+
+static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
+    const uint64_t npad = po_round_up(n ? n : 1, kPadRows);
+    int rc = po_buf_reserve(ctx, &ctx->ws_rowstat, 4 * npad * sizeof(double));
+    if (rc) return rc;
+    if (metric != PO_KT) {
+        rc = po_buf_reserve(ctx, &ctx->ws_freq, (uint64_t)dim * npad * sizeof(double));
+        if (rc) return rc;
+    } else {
+        rc = po_buf_reserve(ctx, &ctx->ws_aux, n * (uint64_t)dim * sizeof(uint32_t));
+        if (rc) return rc;
+    }
+    if (metric == PO_JSD) {
+        rc = po_logtab_init(ctx);
+        if (rc) return rc;
+    }
+    return PO_OK;
+}
+
+extern "C" int po_pairwise_reserve(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
+    PO_REQUIRE(ctx != nullptr, "po_pairwise_reserve: ctx is NULL");
+    int rc = check_metric(metric);
+    if (rc) return rc;
+    PO_HIP(hipSetDevice(ctx->device));
+    return reserve_pairwise(ctx, n, dim, metric);
+}
+
+// Exactly one of (d_counts,d_totals) / d_freq is given.
+static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts, const uint64_t* d_totals,
+                         const double* d_freq, uint64_t n, uint32_t dim, int metric, uint64_t row_begin,
+                         uint64_t row_end, int out_dtype, void* d_out, uint64_t ld_out, uint32_t flags,
+                         po_stats* stats) {
+    PO_REQUIRE(ctx != nullptr, "%s: ctx is NULL", who);
+    int rc = check_metric(metric);
+    if (rc) return rc;
+    PO_REQUIRE(out_dtype == PO_F64 || out_dtype == PO_F32, "%s: out_dtype must be PO_F64 or PO_F32", who);
+    PO_REQUIRE(row_begin <= row_end && row_end <= n, "%s: row range [%llu,%llu) outside 0..%llu", who,
+               (unsigned long long)row_begin, (unsigned long long)row_end, (unsigned long long)n);
+    PO_REQUIRE(dim >= 1, "%s: dim must be positive", who);
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n == 0 || row_begin == row_end) return PO_OK;
+    PO_REQUIRE((d_freq != nullptr || (d_counts != nullptr && d_totals != nullptr)) && d_out != nullptr, "%s: NULL buffer", who);
+    PO_REQUIRE(ld_out >= n, "%s: ld_out (%llu) < n (%llu)", who, (unsigned long long)ld_out, (unsigned long long)n);
+    PO_HIP(hipSetDevice(ctx->device));
+
+    rc = reserve_pairwise(ctx, n, dim, metric);
+    if (rc) return rc;
+    const uint64_t npad = po_round_up(n, kPadRows);
+    double* ft = static_cast<double*>(ctx->ws_freq.p);
+    double* rowstat = static_cast<double*>(ctx->ws_rowstat.p);
+
+    po_tile_args a;
+    a.ft = ft;
+    a.rowstat = rowstat;
+    a.n = n;
+    a.npad = npad;
+    a.dim = dim;
+    a.row_begin = row_begin;
+    a.row_end = row_end;
+    a.out = d_out;
+    a.ld_out = ld_out;
+    a.out_f32 = (out_dtype == PO_F32);
+    a.symmetric = (row_begin == 0 && row_end == n && !(flags & PO_FLAG_NO_SYMMETRY)) ? 1 : 0;
+
+    if (stats) PO_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    // ---- prep: working layout + per-row terms ----
+    uint32_t* lessrank = nullptr;
+    if (metric == PO_EUCL || metric == PO_JSD || metric == PO_BC) {
+        rc = d_freq ? po_launch_prep_freq(ctx, d_freq, n, dim, npad, ft)
+                    : po_launch_prep(ctx, d_counts, d_totals, n, dim, npad, ft);
+        if (rc) return rc;
+    }
+    if (metric == PO_JSD || metric == PO_BC) {
+        rc = po_launch_rowstat(ctx, ft, n, dim, npad, rowstat);
+    } else if (metric == PO_SC) {
+        rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, ft, nullptr, rowstat);
+    } else if (metric == PO_KT) {
+        lessrank = static_cast<uint32_t*>(ctx->ws_aux.p);
+        rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, nullptr, lessrank, rowstat);
+    }
+    if (rc) return rc;
+    if (stats) PO_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    // ---- tiles ----
+    uint64_t tiles = 0;
+    uint32_t kid = 0;
+    switch (metric) {
+        case PO_JSD: rc = po_launch_valu_tiles(ctx, PO_JSD, a, &tiles); kid = PO_KERNEL_VALU_JSD; break;
+        case PO_BC: rc = po_launch_valu_tiles(ctx, PO_BC, a, &tiles); kid = PO_KERNEL_VALU_BC; break;
+        case PO_EUCL: rc = po_launch_gram_f64(ctx, PO_EUCL, a, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
+        case PO_SC: rc = po_launch_gram_f64(ctx, PO_SC, a, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
+        case PO_KT: rc = po_launch_kt(ctx, lessrank, n, dim, a, &tiles); kid = PO_KERNEL_VALU_KT; break;
+    }
+    if (rc) return rc;
+    if (stats) {
+        PO_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+        PO_HIP(hipEventSynchronize(ctx->ev[2]));
+        float ms = 0.f;
+        PO_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        stats->prep_ms = ms;
+        PO_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+        stats->kernel_ms = ms;
+        PO_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[2]));
+        stats->total_ms = ms;
+        stats->pairs = (row_end - row_begin) * n / 2;
+        stats->tiles = tiles;
+        stats->kernel_id = kid;
+    }
+    return PO_OK;
+}
+
+extern "C" int po_pairwise_dev(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
+                               uint32_t dim, int metric, uint64_t row_begin, uint64_t row_end, int out_dtype,
+                               void* d_out, uint64_t ld_out, uint32_t flags, po_stats* stats) {
+    if (n && row_begin != row_end && (!d_counts || !d_totals)) { po_set_error("po_pairwise_dev: NULL buffer"); return PO_EINVAL; }
+    return pairwise_core(ctx, "po_pairwise_dev", d_counts, d_totals, nullptr, n, dim, metric, row_begin, row_end,
+                         out_dtype, d_out, ld_out, flags, stats);
+}
+
+extern "C" int po_pairwise_freq_dev(po_ctx* ctx, const double* d_freq, uint64_t n, uint32_t dim, int metric,
+                                    uint64_t row_begin, uint64_t row_end, int out_dtype, void* d_out,
+                                    uint64_t ld_out, uint32_t flags, po_stats* stats) {
+    if (n && row_begin != row_end && !d_freq) { po_set_error("po_pairwise_freq_dev: NULL buffer"); return PO_EINVAL; }
+    return pairwise_core(ctx, "po_pairwise_freq_dev", nullptr, nullptr, d_freq, n, dim, metric, row_begin, row_end,
+                         out_dtype, d_out, ld_out, flags, stats);
+}
+
+// host-pointer forms: stage in ws_io, run the device form, copy the rows back
+static int pairwise_host(po_ctx* ctx, const char* who, const uint32_t* counts, const uint64_t* totals,
+                         const double* freq, uint64_t n, uint32_t dim, int metric, uint64_t row_begin,
+                         uint64_t row_end, int out_dtype, void* out, uint64_t ld_out, uint32_t flags,
+                         po_stats* stats) {
+    PO_REQUIRE(ctx != nullptr, "%s: ctx is NULL", who);
+    int rc = check_metric(metric);
+    if (rc) return rc;
+    PO_REQUIRE(out_dtype == PO_F64 || out_dtype == PO_F32, "%s: out_dtype must be PO_F64 or PO_F32", who);
+    PO_REQUIRE(row_begin <= row_end && row_end <= n, "%s: row range [%llu,%llu) outside 0..%llu", who,
+               (unsigned long long)row_begin, (unsigned long long)row_end, (unsigned long long)n);
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n == 0 || row_begin == row_end) return PO_OK;
+    PO_REQUIRE((freq != nullptr || (counts != nullptr && totals != nullptr)) && out != nullptr, "%s: NULL buffer", who);
+    PO_REQUIRE(ld_out >= n, "%s: ld_out (%llu) < n (%llu)", who, (unsigned long long)ld_out, (unsigned long long)n);
+    PO_REQUIRE(dim >= 1, "%s: dim must be positive", who);
+    PO_HIP(hipSetDevice(ctx->device));
+
+    const size_t esz = (out_dtype == PO_F32) ? 4 : 8;
+    const uint64_t rows = row_end - row_begin;
+    const size_t b_in = po_round_up(n * (uint64_t)dim * (freq ? sizeof(double) : sizeof(uint32_t)), 256);
+    const size_t b_tot = po_round_up(n * sizeof(uint64_t), 256);
+    const size_t b_out = rows * n * esz;
+    rc = po_buf_reserve(ctx, &ctx->ws_io, b_in + b_tot + b_out);
+    if (rc) return rc;
+    uint8_t* base = static_cast<uint8_t*>(ctx->ws_io.p);
+    void* d_in = base;
+    uint64_t* d_tot = reinterpret_cast<uint64_t*>(base + b_in);
+    void* d_out = base + b_in + b_tot;
+    if (freq) {
+        PO_HIP(hipMemcpyAsync(d_in, freq, n * (uint64_t)dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        rc = pairwise_core(ctx, who, nullptr, nullptr, static_cast<const double*>(d_in), n, dim, metric, row_begin,
+                           row_end, out_dtype, d_out, n, flags, stats);
+    } else {
+        PO_HIP(hipMemcpyAsync(d_in, counts, n * (uint64_t)dim * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        PO_HIP(hipMemcpyAsync(d_tot, totals, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        rc = pairwise_core(ctx, who, static_cast<const uint32_t*>(d_in), d_tot, nullptr, n, dim, metric, row_begin,
+                           row_end, out_dtype, d_out, n, flags, stats);
+    }
+    if (rc) return rc;
+    PO_HIP(hipMemcpy2DAsync(out, ld_out * esz, d_out, n * esz, n * esz, rows, hipMemcpyDeviceToHost, ctx->stream));
+    PO_HIP(hipStreamSynchronize(ctx->stream));
+    return PO_OK;
+}
+
+extern "C" int po_pairwise(po_ctx* ctx, const uint32_t* counts, const uint64_t* totals, uint64_t n, uint32_t dim,
+                           int metric, uint64_t row_begin, uint64_t row_end, int out_dtype, void* out,
+                           uint64_t ld_out, uint32_t flags, po_stats* stats) {
+    if (n && row_begin != row_end && (!counts || !totals)) { po_set_error("po_pairwise: NULL buffer"); return PO_EINVAL; }
+    return pairwise_host(ctx, "po_pairwise", counts, totals, nullptr, n, dim, metric, row_begin, row_end, out_dtype,
+                         out, ld_out, flags, stats);
+}
+
+extern "C" int po_pairwise_freq(po_ctx* ctx, const double* freq, uint64_t n, uint32_t dim, int metric,
+                                uint64_t row_begin, uint64_t row_end, int out_dtype, void* out, uint64_t ld_out,
+                                uint32_t flags, po_stats* stats) {
+    if (n && row_begin != row_end && !freq) { po_set_error("po_pairwise_freq: NULL buffer"); return PO_EINVAL; }
+    return pairwise_host(ctx, "po_pairwise_freq", nullptr, nullptr, freq, n, dim, metric, row_begin, row_end,
+                         out_dtype, out, ld_out, flags, stats);
+}

@@ -1,0 +1,215 @@
+// Stage 2, Gram-form metrics on the float64 matrix cores: Euclidean distance and Spearman.
+//
+// Replaces one Python call per contig pair
+//   phylodist.Eucl  (/root/reference/phylopackage/core/phylodist.py:36-41)
+//   phylodist.SC    (/root/reference/phylopackage/core/phylodist.py:82-85, as intended)
+// under sklearn's pairwise_distances (/root/reference/phylopackage/bin/phyloligo.py:364-392).
+//
+//   Eucl(a,b)^2 = |a|^2 + |b|^2 - 2 a.b            SC(a,b) = 1 - r_a.r_b / sqrt(|r_a|^2 |r_b|^2)
+// (r = centred average ranks).  The dot products are a dense X X^T over the transposed
+// float64 operand matrix Xt[d][npad]: v_mfma_f64_16x16x4_f64, 128 x 128 tile per workgroup,
+// 64 x 64 per wave (4 x 4 MFMA tiles, 64 float64 accumulators per lane), operands staged
+// 8 words at a time through double-buffered LDS.  The squared norms come from the SAME
+// instruction sequence run on the diagonal 16 x 16 blocks, so that two identical records give
+// |a|^2 + |a|^2 - 2 a.a = 0 exactly, as the reference's (a-b)^2 form does.
+#include "po_internal.h"
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 128, TN = 128;
+constexpr int KC = 8;
+constexpr int kThreads = 256;
+constexpr int kRowStride = TM + TN + 16;          // +16 doubles: k-rows of one MFMA operand land in
+constexpr int kStageDoubles = KC * kRowStride;    // different bank halves (ds_read_b64, 32-lane groups)
+
+struct TileCoord { uint32_t ti, tj; };
+
+__device__ __forceinline__ TileCoord tri_decode(uint64_t b, uint32_t T) {
+    const double tt = 2.0 * T + 1.0;
+    uint32_t i = (uint32_t)((tt - sqrt(tt * tt - 8.0 * (double)b)) * 0.5);
+    auto before = [T](uint64_t r) { return r * T - r * (r - 1) / 2; };
+    while (i > 0 && before(i) > b) --i;
+    while (before((uint64_t)i + 1) <= b) ++i;
+    return {i, (uint32_t)(i + (b - before(i)))};
+}
+
+template <typename T> __device__ __forceinline__ void store_out(void* out, uint64_t idx, double v);
+template <> __device__ __forceinline__ void store_out<double>(void* out, uint64_t idx, double v) {
+    static_cast<double*>(out)[idx] = v;
+}
+template <> __device__ __forceinline__ void store_out<float>(void* out, uint64_t idx, double v) {
+    static_cast<float*>(out)[idx] = (float)v;
+}
+
+// |x_r|^2 for 16 records per wave, by the same k-ascending MFMA chain the tile kernel uses.
+__global__ __launch_bounds__(64) void gram_diag_kernel(const double* __restrict__ xt, uint32_t dim, uint64_t npad,
+                                                       double* __restrict__ norms) {
+    const uint32_t l = threadIdx.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * 16;
+    const uint32_t c = l & 15, g = l >> 4;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (uint32_t k0 = 0; k0 < dim; k0 += 4) {
+        const uint32_t k = k0 + g;
+        const double v = (k < dim) ? xt[(uint64_t)k * npad + r0 + c] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+    }
+    // lane holds rows g, g+4, g+8, g+12 of column c; the diagonal element of c sits where row == c
+    if ((c & 3u) == g) {
+        const uint32_t reg = (c - g) >> 2;
+        const double d = reg == 0 ? acc[0] : reg == 1 ? acc[1] : reg == 2 ? acc[2] : acc[3];
+        norms[r0 + c] = d;
+    }
+}
+
+template <int METRIC, typename OUT>
+__global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, const double* __restrict__ norms,
+                                                                uint32_t tiles_n, uint32_t tile_row0) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* stage = reinterpret_cast<double*>(smem);                    // [2][KC][kRowStride]
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t lane = t & 63, wave = t >> 6;
+    const uint32_t wr = wave >> 1, wc = wave & 1;                       // 2 x 2 waves of 64 x 64
+    const uint32_t lc = lane & 15, lg = lane >> 4;
+
+    uint32_t ti, tj;
+    if (A.symmetric) {
+        const TileCoord c = tri_decode(blockIdx.x, tiles_n);
+        ti = c.ti; tj = c.tj;
+    } else {
+        ti = tile_row0 + blockIdx.x / tiles_n;
+        tj = blockIdx.x % tiles_n;
+    }
+    const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    const uint32_t sk = t >> 5, sc = (t & 31) * 4;
+    const double* gA = A.ft + i0 + sc;
+    const double* gB = A.ft + j0 + sc;
+    double2 ra0, ra1, rb0, rb1;
+    auto gload = [&](uint32_t k0) {
+        const uint32_t k = k0 + sk;
+        if (k < A.dim) {
+            const double* pa = gA + (uint64_t)k * A.npad;
+            const double* pb = gB + (uint64_t)k * A.npad;
+            ra0 = *reinterpret_cast<const double2*>(pa);
+            ra1 = *reinterpret_cast<const double2*>(pa + 2);
+            rb0 = *reinterpret_cast<const double2*>(pb);
+            rb1 = *reinterpret_cast<const double2*>(pb + 2);
+        } else {
+            ra0 = ra1 = rb0 = rb1 = make_double2(0.0, 0.0);
+        }
+    };
+    auto sstore = [&](uint32_t buf) {
+        double* s = stage + buf * kStageDoubles + sk * kRowStride;
+        *reinterpret_cast<double2*>(s + sc) = ra0;
+        *reinterpret_cast<double2*>(s + sc + 2) = ra1;
+        *reinterpret_cast<double2*>(s + TM + sc) = rb0;
+        *reinterpret_cast<double2*>(s + TM + sc + 2) = rb1;
+    };
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+
+    uint32_t cur = 0;
+    for (uint32_t k0 = 0; k0 < A.dim; k0 += KC) {
+        const bool more = k0 + KC < A.dim;
+        if (more) gload(k0 + KC);
+        const double* s = stage + cur * kStageDoubles;
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            const double* srow = s + (ks * 4 + lg) * kRowStride;
+            double a[4], b[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                a[m] = srow[wr * 64 + m * 16 + lc];
+                b[m] = srow[TM + wc * 64 + m * 16 + lc];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        if (more) sstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane holds rows lg + 4*reg, column lc of each 16 x 16 block -------------------
+    const bool mirror = A.symmetric && (ti != tj);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const uint64_t j = j0 + wc * 64 + n * 16 + lc;
+        if (j >= A.n) continue;
+        const double nj = norms[j];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const uint64_t i = i0 + wr * 64 + m * 16 + lg + 4 * reg;
+                if (i < A.row_begin || i >= A.row_end) continue;
+                const double g = acc[m][n][reg];
+                const double ni = norms[i];
+                double v;
+                if (METRIC == PO_EUCL) {
+                    v = sqrt(fmax((ni + nj) - 2.0 * g, 0.0));
+                    if (i == j) v = 0.0;
+                } else {  // PO_SC: 1 - Pearson correlation of the centred ranks; constant row -> NaN
+                    v = 1.0 - g / sqrt(ni * nj);
+                }
+                store_out<OUT>(A.out, (i - A.row_begin) * A.ld_out + j, v);
+                if (mirror) store_out<OUT>(A.out, j * A.ld_out + i, v);
+            }
+        }
+    }
+}
+
+template <int METRIC>
+int launch_gram(po_ctx* ctx, const po_tile_args& a, const double* norms, uint64_t* tiles) {
+    const uint32_t T = (uint32_t)((a.n + TN - 1) / TN);
+    uint64_t nblocks;
+    uint32_t tile_row0 = 0;
+    if (a.symmetric) {
+        nblocks = (uint64_t)T * (T + 1) / 2;
+    } else {
+        tile_row0 = (uint32_t)(a.row_begin / TM);
+        const uint32_t tile_row1 = (uint32_t)((a.row_end + TM - 1) / TM);
+        nblocks = (uint64_t)(tile_row1 - tile_row0) * T;
+    }
+    if (tiles) *tiles = nblocks;
+    if (nblocks == 0) return PO_OK;
+    if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
+    const size_t shmem = 2 * kStageDoubles * sizeof(double);
+    if (a.out_f32) {
+        hipLaunchKernelGGL((gram_tile_kernel<METRIC, float>), dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream,
+                           a, norms, T, tile_row0);
+    } else {
+        hipLaunchKernelGGL((gram_tile_kernel<METRIC, double>), dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream,
+                           a, norms, T, tile_row0);
+    }
+    PO_CHECK_LAUNCH("gram_tile_kernel");
+    return PO_OK;
+}
+
+}  // namespace
+
+// a.ft is the operand matrix (frequencies for Eucl, centred ranks for SC); the squared norms go
+// to rowstat[2][npad].
+int po_launch_gram_f64(po_ctx* ctx, int metric, const po_tile_args& a, uint64_t* tiles) {
+    double* norms = const_cast<double*>(a.rowstat) + 2 * a.npad;
+    hipLaunchKernelGGL(gram_diag_kernel, dim3((uint32_t)(a.npad / 16)), dim3(64), 0, ctx->stream, a.ft, a.dim, a.npad, norms);
+    PO_CHECK_LAUNCH("gram_diag_kernel");
+    if (metric == PO_EUCL) return launch_gram<PO_EUCL>(ctx, a, norms, tiles);
+    if (metric == PO_SC) return launch_gram<PO_SC>(ctx, a, norms, tiles);
+    po_set_error("po_launch_gram_f64: metric %d is not a Gram-form metric", metric);
+    return PO_EINVAL;
+}

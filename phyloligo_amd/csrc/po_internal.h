@@ -1,0 +1,121 @@
+// Internal declarations shared by the translation units of libphyloligo_amd.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "phyloligo_amd.h"
+
+// ---- error plumbing --------------------------------------------------------------------
+void po_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define PO_HIP(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            po_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (e__ == hipErrorOutOfMemory) ? PO_ENOMEM : PO_EHIP;                     \
+        }                                                                                  \
+    } while (0)
+
+#define PO_CHECK_LAUNCH(name)                                                              \
+    do {                                                                                   \
+        hipError_t e__ = hipGetLastError();                                                \
+        if (e__ != hipSuccess) {                                                           \
+            po_set_error("launch of %s failed: %s", name, hipGetErrorString(e__));         \
+            return PO_EHIP;                                                                \
+        }                                                                                  \
+    } while (0)
+
+#define PO_REQUIRE(cond, ...)                                                              \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            po_set_error(__VA_ARGS__);                                                     \
+            return PO_EINVAL;                                                              \
+        }                                                                                  \
+    } while (0)
+
+// ---- context ---------------------------------------------------------------------------
+// A growable device buffer owned by the context (never freed before po_ctx_destroy, so the
+// steady state of repeated calls does no hipMalloc).
+struct po_buf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct po_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // caller's stream (not owned) or the default stream
+    hipDeviceProp_t prop;
+    po_buf ws_freq;                    // Ft: float64 [dim][npad] transposed frequencies
+    po_buf ws_rowstat;                 // per-row terms (entropy, norm, ...), float64 [4][npad]
+    po_buf ws_aux;                     // metric specific (ranks, sign expansions, chunk tables)
+    po_buf ws_io;                      // staging of the host-pointer entry points
+    po_buf ws_logtab;                  // replicated log table of the JSD kernel
+    bool logtab_ready = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+int po_buf_reserve(po_ctx* ctx, po_buf* b, size_t bytes);
+
+// ---- pattern ---------------------------------------------------------------------------
+#define PO_MAX_WINDOW 32
+#define PO_MAX_K 8
+#define PO_MAX_RUNS 16
+
+// A spaced-word pattern compiled for the rolling 2-bit window register: the word index is
+// the OR over runs of ((reg >> src_shift) & mask) << dst_shift.
+struct po_pattern {
+    uint32_t window;   // W = len(pattern)
+    uint32_t k;        // number of '1'
+    uint32_t dim;      // 4^k
+    uint32_t nruns;
+    uint32_t src_shift[PO_MAX_RUNS];
+    uint32_t dst_shift[PO_MAX_RUNS];
+    uint32_t mask[PO_MAX_RUNS];
+    uint32_t ones[PO_MAX_WINDOW];  // positions of the '1's (junction words are built from these)
+};
+int po_pattern_compile(const char* pattern, po_pattern* out);
+
+// ---- kernels (one launcher per translation unit) -----------------------------------------
+int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets, uint64_t n_seqs,
+                    uint64_t total_bytes, const po_pattern& pat, int strand, uint32_t* d_counts,
+                    uint64_t* d_totals);
+
+// Working layout of stage 2: Ft[d][npad] = counts[n][d] / totals[n] (float64, zero padded).
+int po_launch_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                   uint64_t npad, double* d_ft);
+int po_launch_prep_freq(po_ctx* ctx, const double* d_freq, uint64_t n, uint32_t dim, uint64_t npad, double* d_ft);
+int po_launch_freq_rowmajor(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
+                            uint32_t dim, double* d_freq);
+// rowstat[0][n] = sum f ln f, rowstat[1][n] = sum f
+int po_launch_rowstat(po_ctx* ctx, const double* d_ft, uint64_t n, uint32_t dim, uint64_t npad, double* d_rowstat);
+
+struct po_tile_args {
+    const double* ft;       // [dim][npad]
+    const double* rowstat;  // [4][npad]
+    uint64_t n, npad;
+    uint32_t dim;
+    uint64_t row_begin, row_end;   // output rows
+    void* out;
+    uint64_t ld_out;
+    int out_f32;
+    int symmetric;          // 1: only tiles on/above the diagonal are computed, mirrored on store
+};
+int po_launch_valu_tiles(po_ctx* ctx, int metric, const po_tile_args& a, uint64_t* tiles);
+int po_launch_gram_f64(po_ctx* ctx, int metric, const po_tile_args& a, uint64_t* tiles);
+int po_logtab_init(po_ctx* ctx);
+
+// KT / SC helpers.  Order statistics of every record, from counts (uint32) or frequencies (float64):
+//   d_rt        centred average ranks, float64 [dim][npad]   (may be NULL)
+//   d_lessrank  number of strictly smaller words, uint32 [n][dim]: same order and ties as the
+//               input, which is all Kendall's tau looks at            (may be NULL)
+//   rowstat[3]  number of tied word pairs of the record
+int po_launch_ranks(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint64_t n, uint32_t dim,
+                    uint64_t npad, double* d_rt, uint32_t* d_lessrank, double* d_rowstat);
+int po_launch_kt(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, const po_tile_args& a,
+                 uint64_t* tiles);
+
+static inline uint64_t po_round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }

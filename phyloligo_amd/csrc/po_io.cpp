@@ -1,0 +1,132 @@
+// Host-side formats either side of the path: FASTA ingest and the text .mat writer.
+//
+// FASTA: the reference iterates Bio.SeqIO.parse(genome, "fasta") and uses str(record.seq)
+// (/root/reference/phylopackage/bin/phyloligo.py:869).  Biopython is third-party and absent from
+// the reference tree; the semantics restated here are those of its SimpleFastaParser: a record
+// opens at a line whose first byte is '>', the title is the rest of that line right-stripped,
+// the sequence is the following lines each right-stripped and joined, with every ' ' and '\r'
+// removed.  Blank lines before the first record are skipped; any other text there is an error.
+//
+// .mat: numpy.savetxt(path, m, delimiter="\t") (/root/reference/phylopackage/bin/phyloligo.py:1061,
+// :1066) = "%.18e" per value, '\t' between columns, '\n' after every row, nothing else.
+#include <errno.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "phyloligo_amd.h"
+
+void po_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+namespace {
+
+inline bool is_py_space(uint8_t c) {  // bytes.rstrip() / str.rstrip() default set for ASCII
+    return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0x0b || c == 0x0c;
+}
+
+// Walks the records; with seq_out == NULL only counts.  Returns 0 or PO_EIO.
+int fasta_walk(const uint8_t* data, uint64_t len, uint8_t* seq_out, uint64_t* offsets_out, uint64_t* title_begin,
+               uint64_t* title_end, uint64_t* n_records, uint64_t* seq_bytes) {
+    uint64_t pos = 0, nrec = 0, nout = 0;
+    bool in_record = false;
+    while (pos < len) {
+        const uint8_t* nl = static_cast<const uint8_t*>(memchr(data + pos, '\n', len - pos));
+        const uint64_t line_end = nl ? (uint64_t)(nl - data) : len;   // exclusive, without the '\n'
+        uint64_t e = line_end;
+        while (e > pos && is_py_space(data[e - 1])) --e;              // rstrip
+        if (data[pos] == '>' && line_end > pos) {
+            if (offsets_out) offsets_out[nrec] = nout;
+            if (title_begin) title_begin[nrec] = pos + 1;
+            if (title_end) title_end[nrec] = (e > pos + 1) ? e : pos + 1;
+            ++nrec;
+            in_record = true;
+        } else if (!in_record) {
+            if (e > pos) {
+                po_set_error("FASTA input does not start with '>' (byte %llu)", (unsigned long long)pos);
+                return PO_EIO;
+            }
+        } else {
+            for (uint64_t i = pos; i < e; ++i) {
+                const uint8_t c = data[i];
+                if (c == ' ' || c == '\r') continue;
+                if (seq_out) seq_out[nout] = c;
+                ++nout;
+            }
+        }
+        pos = nl ? line_end + 1 : len;
+    }
+    if (offsets_out) offsets_out[nrec] = nout;
+    if (n_records) *n_records = nrec;
+    if (seq_bytes) *seq_bytes = nout;
+    return PO_OK;
+}
+
+}  // namespace
+
+extern "C" int po_fasta_scan(const uint8_t* data, uint64_t len, uint64_t* n_records, uint64_t* seq_bytes) {
+    if ((!data && len) || !n_records || !seq_bytes) {
+        po_set_error("po_fasta_scan: NULL argument");
+        return PO_EINVAL;
+    }
+    return fasta_walk(data, len, nullptr, nullptr, nullptr, nullptr, n_records, seq_bytes);
+}
+
+extern "C" int po_fasta_extract(const uint8_t* data, uint64_t len, uint8_t* seq_out, uint64_t* offsets_out,
+                                uint64_t* title_begin, uint64_t* title_end) {
+    if ((!data && len) || !offsets_out) {
+        po_set_error("po_fasta_extract: NULL argument");
+        return PO_EINVAL;
+    }
+    uint8_t dummy;
+    return fasta_walk(data, len, seq_out ? seq_out : &dummy, offsets_out, title_begin, title_end, nullptr, nullptr);
+}
+
+extern "C" int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, uint64_t ld, const char* path,
+                                 int append) {
+    if (!path || (!m && rows && cols) || ld < cols) {
+        po_set_error("po_write_mat_text: bad argument");
+        return PO_EINVAL;
+    }
+    FILE* fh = fopen(path, append ? "ab" : "wb");
+    if (!fh) {
+        po_set_error("cannot open %s: %s", path, strerror(errno));
+        return PO_EIO;
+    }
+    const size_t cap = 1u << 20;
+    char* buf = static_cast<char*>(malloc(cap + 64));
+    if (!buf) {
+        fclose(fh);
+        po_set_error("po_write_mat_text: out of memory");
+        return PO_ENOMEM;
+    }
+    size_t used = 0;
+    int rc = PO_OK;
+    for (uint64_t r = 0; r < rows && rc == PO_OK; ++r) {
+        for (uint64_t c = 0; c < cols; ++c) {
+            const double v = m[r * ld + c];
+            if (isnan(v)) {
+                memcpy(buf + used, "nan", 3);
+                used += 3;
+            } else if (isinf(v)) {
+                const char* s = v < 0 ? "-inf" : "inf";
+                const size_t l = strlen(s);
+                memcpy(buf + used, s, l);
+                used += l;
+            } else {
+                used += (size_t)snprintf(buf + used, 40, "%.18e", v);
+            }
+            buf[used++] = (c + 1 == cols) ? '\n' : '\t';
+            if (used >= cap) {
+                if (fwrite(buf, 1, used, fh) != used) { rc = PO_EIO; break; }
+                used = 0;
+            }
+        }
+    }
+    if (rc == PO_OK && used && fwrite(buf, 1, used, fh) != used) rc = PO_EIO;
+    free(buf);
+    if (fclose(fh) != 0) rc = PO_EIO;
+    if (rc != PO_OK) po_set_error("write to %s failed: %s", path, strerror(errno));
+    return rc;
+}

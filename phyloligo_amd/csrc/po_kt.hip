@@ -1,0 +1,195 @@
+// Stage 2, rank metrics: Kendall tau (KT) tiles, and the per-record order statistics both
+// rank metrics need (average ranks for Spearman, tie counts for Kendall).
+//
+// Replaces  phylodist.KT  (/root/reference/phylopackage/core/phylodist.py:71-74):
+//     1 - Bio.Cluster.distancematrix((a,b), dist="k")[1][0]
+// The C Clustering Library's Kendall distance is 1 - tau with
+//     tau = (con - dis) / sqrt((con+dis+exx) (con+dis+exy)),   distance 1 if a factor is 0,
+// con/dis = concordant/discordant word pairs, exx/exy = pairs tied in one vector only.  With
+// T = D(D-1)/2 word pairs and t_x = pairs tied in x:  con+dis+exx = T - t_y, con+dis+exy = T - t_x,
+// so only  S = con - dis = sum_{p<q} sgn(x_p - x_q) sgn(y_p - y_q)  depends on the record pair.
+// Ranks and ties of frequencies equal those of the integer counts (same positive divisor per
+// record), so everything here is exact integer work until the final division.
+#include "po_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int PT = 16;            // 16 x 16 record pairs per workgroup, one pair per lane
+constexpr int CH = 128;           // words per staged chunk
+constexpr int kRow = CH + 1;      // +1: rows of a chunk start in different banks
+
+// One workgroup per record, input row major (uint32 counts or float64 frequencies).
+//   rt[d][npad]      centred average rank of word d:  #less + (#equal - D)/2
+//   lessrank[r][d]   #less (an integer with the order and ties of the input)
+//   rowstat[3][r]    number of word pairs tied in the record
+template <typename T>
+__global__ __launch_bounds__(kThreads) void row_order_kernel(const T* __restrict__ rows, uint64_t n, uint32_t dim,
+                                                             uint64_t npad, double* __restrict__ rt,
+                                                             uint32_t* __restrict__ lessrank,
+                                                             double* __restrict__ rowstat) {
+    __shared__ T chunk[2048];
+    __shared__ unsigned long long tied;
+    const uint64_t r = blockIdx.x;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) tied = 0;
+    const T* row = rows + r * dim;
+    unsigned long long my_tied = 0;
+    for (uint32_t base = 0; base < dim; base += kThreads) {          // words owned by lanes this round
+        const uint32_t d = base + t;
+        const T x = (d < dim) ? row[d] : T(0);
+        uint32_t less = 0, equal = 0;
+        for (uint32_t c0 = 0; c0 < dim; c0 += 2048) {
+            const uint32_t len = min(2048u, dim - c0);
+            __syncthreads();
+            for (uint32_t i = t; i < len; i += kThreads) chunk[i] = row[c0 + i];
+            __syncthreads();
+            for (uint32_t i = 0; i < len; ++i) {
+                const T y = chunk[i];
+                less += (y < x);
+                equal += (y == x);
+            }
+        }
+        if (d < dim) {
+            if (rt) rt[(uint64_t)d * npad + r] = (double)less + 0.5 * ((double)equal - (double)dim);
+            if (lessrank) lessrank[r * dim + d] = less;
+            my_tied += equal - 1;                                    // ordered tied partners of word d
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) my_tied += __shfl_down(my_tied, o, 64);
+    __syncthreads();
+    if ((t & 63u) == 0) atomicAdd(&tied, my_tied);
+    __syncthreads();
+    if (t == 0) rowstat[3 * npad + r] = (double)(tied / 2);
+}
+
+__global__ __launch_bounds__(kThreads) void zero_pad_kernel(double* __restrict__ rt, uint64_t n, uint32_t dim,
+                                                            uint64_t npad) {
+    const uint64_t pad = npad - n;
+    const uint64_t total = pad * dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
+        rt[(i / pad) * npad + n + (i % pad)] = 0.0;
+}
+
+struct TileCoord { uint32_t ti, tj; };
+__device__ __forceinline__ TileCoord tri_decode(uint64_t b, uint32_t T) {
+    const double tt = 2.0 * T + 1.0;
+    uint32_t i = (uint32_t)((tt - sqrt(tt * tt - 8.0 * (double)b)) * 0.5);
+    auto before = [T](uint64_t r) { return r * T - r * (r - 1) / 2; };
+    while (i > 0 && before(i) > b) --i;
+    while (before((uint64_t)i + 1) <= b) ++i;
+    return {i, (uint32_t)(i + (b - before(i)))};
+}
+
+__device__ __forceinline__ int sgn_i32(int v) { return min(max(v, -1), 1); }   // v_med3_i32
+
+template <typename OUT>
+__global__ __launch_bounds__(kThreads) void kt_tile_kernel(const uint32_t* __restrict__ counts, po_tile_args A,
+                                                           uint32_t tiles_n, uint32_t tile_row0) {
+    __shared__ int xa_p[PT][kRow], xb_p[PT][kRow], xa_q[PT][kRow], xb_q[PT][kRow];
+    const uint32_t t = threadIdx.x;
+    const uint32_t pi = t >> 4, pj = t & 15;
+    uint32_t ti, tj;
+    if (A.symmetric) {
+        const TileCoord c = tri_decode(blockIdx.x, tiles_n);
+        ti = c.ti; tj = c.tj;
+    } else {
+        ti = tile_row0 + blockIdx.x / tiles_n;
+        tj = blockIdx.x % tiles_n;
+    }
+    const uint64_t i0 = (uint64_t)ti * PT, j0 = (uint64_t)tj * PT;
+
+    auto load_chunk = [&](int (*dst)[kRow], uint64_t r0, uint32_t c0) {
+        for (uint32_t e = t; e < PT * CH; e += kThreads) {
+            const uint32_t rr = e / CH, cc = e % CH;
+            const uint64_t r = r0 + rr;
+            dst[rr][cc] = (r < A.n && c0 + cc < A.dim) ? (int)counts[r * A.dim + c0 + cc] : 0;
+        }
+    };
+
+    long long S = 0;
+    for (uint32_t p0 = 0; p0 < A.dim; p0 += CH) {
+        __syncthreads();
+        load_chunk(xa_p, i0, p0);
+        load_chunk(xb_p, j0, p0);
+        const uint32_t plen = min((uint32_t)CH, A.dim - p0);
+        for (uint32_t q0 = p0; q0 < A.dim; q0 += CH) {
+            __syncthreads();
+            load_chunk(xa_q, i0, q0);
+            load_chunk(xb_q, j0, q0);
+            __syncthreads();
+            const uint32_t qlen = min((uint32_t)CH, A.dim - q0);
+            int s = 0;
+            for (uint32_t p = 0; p < plen; ++p) {
+                const int xp = xa_p[pi][p], yp = xb_p[pj][p];
+                const uint32_t qb = (q0 == p0) ? p + 1 : 0;
+                for (uint32_t q = qb; q < qlen; ++q)
+                    s += sgn_i32(xa_q[pi][q] - xp) * sgn_i32(xb_q[pj][q] - yp);
+            }
+            S += s;
+        }
+    }
+
+    const uint64_t i = i0 + pi, j = j0 + pj;
+    if (i >= A.n || j >= A.n || i < A.row_begin || i >= A.row_end) return;
+    const double T = 0.5 * (double)A.dim * ((double)A.dim - 1.0);
+    const double* ties = A.rowstat + 3 * A.npad;
+    const double dx = T - ties[j], dy = T - ties[i];     // con+dis+exx, con+dis+exy
+    double v;
+    if (dx == 0.0 || dy == 0.0) {
+        v = 1.0 - 1.0;
+    } else {
+        const double tau = (double)S / sqrt(dx * dy);
+        v = 1.0 - (1.0 - tau);
+    }
+    if (A.out_f32) {
+        static_cast<float*>(A.out)[(i - A.row_begin) * A.ld_out + j] = (float)v;
+        if (A.symmetric && ti != tj) static_cast<float*>(A.out)[j * A.ld_out + i] = (float)v;
+    } else {
+        static_cast<double*>(A.out)[(i - A.row_begin) * A.ld_out + j] = v;
+        if (A.symmetric && ti != tj) static_cast<double*>(A.out)[j * A.ld_out + i] = v;
+    }
+}
+
+}  // namespace
+
+int po_launch_ranks(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint64_t n, uint32_t dim,
+                    uint64_t npad, double* d_rt, uint32_t* d_lessrank, double* d_rowstat) {
+    if (n == 0) return PO_OK;
+    if (d_rt && npad > n) {
+        hipLaunchKernelGGL(zero_pad_kernel, dim3(256), dim3(kThreads), 0, ctx->stream, d_rt, n, dim, npad);
+        PO_CHECK_LAUNCH("zero_pad_kernel");
+    }
+    if (d_counts)
+        hipLaunchKernelGGL(row_order_kernel<uint32_t>, dim3((uint32_t)n), dim3(kThreads), 0, ctx->stream, d_counts, n, dim,
+                           npad, d_rt, d_lessrank, d_rowstat);
+    else
+        hipLaunchKernelGGL(row_order_kernel<double>, dim3((uint32_t)n), dim3(kThreads), 0, ctx->stream, d_freq, n, dim,
+                           npad, d_rt, d_lessrank, d_rowstat);
+    PO_CHECK_LAUNCH("row_order_kernel");
+    return PO_OK;
+}
+
+int po_launch_kt(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, const po_tile_args& a,
+                 uint64_t* tiles) {
+    const uint32_t T = (uint32_t)((n + PT - 1) / PT);
+    uint64_t nblocks;
+    uint32_t tile_row0 = 0;
+    if (a.symmetric) {
+        nblocks = (uint64_t)T * (T + 1) / 2;
+    } else {
+        tile_row0 = (uint32_t)(a.row_begin / PT);
+        const uint32_t tile_row1 = (uint32_t)((a.row_end + PT - 1) / PT);
+        nblocks = (uint64_t)(tile_row1 - tile_row0) * T;
+    }
+    if (tiles) *tiles = nblocks;
+    if (nblocks == 0) return PO_OK;
+    if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
+    if (a.out_f32)
+        hipLaunchKernelGGL(kt_tile_kernel<float>, dim3((uint32_t)nblocks), dim3(kThreads), 0, ctx->stream, d_lessrank, a, T, tile_row0);
+    else
+        hipLaunchKernelGGL(kt_tile_kernel<double>, dim3((uint32_t)nblocks), dim3(kThreads), 0, ctx->stream, d_lessrank, a, T, tile_row0);
+    PO_CHECK_LAUNCH("kt_tile_kernel");
+    (void)dim;
+    return PO_OK;
+}

@@ -1,0 +1,113 @@
+// counts -> frequencies (count2freq, /root/reference/phylopackage/bin/phyloligo.py:633-661) in the
+// layouts stage 2 reads, plus the per-row terms the tile kernels fold into their epilogues.
+//
+// Working layout of stage 2:  Ft[d][npad] = counts[n][d] / totals[n]  (float64, transposed so a
+// tile's rows are contiguous along n; columns n..npad-1 are zero).  The division is the same
+// correctly-rounded float64 division the reference performs (int/int true division, :656).
+#include "po_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void prep_transpose_kernel(const uint32_t* __restrict__ counts,
+                                                             const unsigned long long* __restrict__ totals,
+                                                             uint64_t n, uint32_t dim, uint64_t npad,
+                                                             double* __restrict__ ft) {
+    __shared__ double tile[64][65];
+    const uint64_t n0 = (uint64_t)blockIdx.x * 64;
+    const uint32_t d0 = blockIdx.y * 64;
+    const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+    for (uint32_t r = ty; r < 64; r += 4) {                        // r: record within tile, tx: word
+        const uint64_t row = n0 + r;
+        double v = 0.0;
+        if (row < n && d0 + tx < dim) {
+            const unsigned long long tot = totals[row];
+            if (tot) v = (double)counts[row * dim + d0 + tx] / (double)tot;
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (uint32_t r = ty; r < 64; r += 4) {                        // r: word within tile, tx: record
+        if (d0 + r < dim && n0 + tx < npad) ft[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_transpose_freq_kernel(const double* __restrict__ freq, uint64_t n,
+                                                                  uint32_t dim, uint64_t npad, double* __restrict__ ft) {
+    __shared__ double tile[64][65];
+    const uint64_t n0 = (uint64_t)blockIdx.x * 64;
+    const uint32_t d0 = blockIdx.y * 64;
+    const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (uint32_t r = ty; r < 64; r += 4) {
+        const uint64_t row = n0 + r;
+        tile[r][tx] = (row < n && d0 + tx < dim) ? freq[row * dim + d0 + tx] : 0.0;
+    }
+    __syncthreads();
+    for (uint32_t r = ty; r < 64; r += 4) {
+        if (d0 + r < dim && n0 + tx < npad) ft[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void freq_rowmajor_kernel(const uint32_t* __restrict__ counts,
+                                                            const unsigned long long* __restrict__ totals,
+                                                            uint64_t n, uint32_t dim, double* __restrict__ freq) {
+    const uint64_t total = n * (uint64_t)dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long tot = totals[i / dim];
+        freq[i] = tot ? (double)counts[i] / (double)tot : 0.0;
+    }
+}
+
+// rowstat[0][r] = sum_w f ln f   (f > 0 terms), rowstat[1][r] = sum_w f (1 up to rounding, 0 for an empty record)
+// One lane per record, coalesced along n thanks to the transposed layout; the summation order
+// (w ascending) is fixed, so the value is reproducible.
+__global__ __launch_bounds__(256) void rowstat_kernel(const double* __restrict__ ft, uint64_t n, uint32_t dim,
+                                                      uint64_t npad, double* __restrict__ rowstat) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= npad) return;
+    double e = 0.0, s = 0.0;
+    if (r < n) {
+        for (uint32_t d = 0; d < dim; ++d) {
+            const double f = ft[(uint64_t)d * npad + r];
+            if (f > 0.0) e += f * log(f);
+            s += f;
+        }
+    }
+    rowstat[r] = e;
+    rowstat[npad + r] = s;
+}
+
+}  // namespace
+
+int po_launch_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                   uint64_t npad, double* d_ft) {
+    dim3 grid((uint32_t)(npad / 64), (dim + 63) / 64);
+    hipLaunchKernelGGL(prep_transpose_kernel, grid, dim3(256), 0, ctx->stream, d_counts,
+                       reinterpret_cast<const unsigned long long*>(d_totals), n, dim, npad, d_ft);
+    PO_CHECK_LAUNCH("prep_transpose_kernel");
+    return PO_OK;
+}
+
+int po_launch_prep_freq(po_ctx* ctx, const double* d_freq, uint64_t n, uint32_t dim, uint64_t npad, double* d_ft) {
+    dim3 grid((uint32_t)(npad / 64), (dim + 63) / 64);
+    hipLaunchKernelGGL(prep_transpose_freq_kernel, grid, dim3(256), 0, ctx->stream, d_freq, n, dim, npad, d_ft);
+    PO_CHECK_LAUNCH("prep_transpose_freq_kernel");
+    return PO_OK;
+}
+
+int po_launch_freq_rowmajor(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
+                            uint32_t dim, double* d_freq) {
+    if (n == 0) return PO_OK;
+    const uint64_t total = n * (uint64_t)dim;
+    const uint32_t blocks = (uint32_t)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(freq_rowmajor_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_counts,
+                       reinterpret_cast<const unsigned long long*>(d_totals), n, dim, d_freq);
+    PO_CHECK_LAUNCH("freq_rowmajor_kernel");
+    return PO_OK;
+}
+
+int po_launch_rowstat(po_ctx* ctx, const double* d_ft, uint64_t n, uint32_t dim, uint64_t npad, double* d_rowstat) {
+    hipLaunchKernelGGL(rowstat_kernel, dim3((uint32_t)((npad + 255) / 256)), dim3(256), 0, ctx->stream, d_ft, n, dim,
+                       npad, d_rowstat);
+    PO_CHECK_LAUNCH("rowstat_kernel");
+    return PO_OK;
+}

@@ -1,0 +1,152 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors produced by the
+reference's own functions and against the CPU oracle on seeded inputs.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PATTERNS = ["1", "11", "1111", "11111", "1101", "10011", "110101", "11011011"]
+STRANDS = ["both", "plus", "minus"]
+RTOL = 1e-6      # north_star: float distances within 1e-6 relative of the float64 reference
+ATOL = 1e-12     # floor for entries whose reference value is exactly 0 (duplicates, diagonal)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import phyloligo_amd as pa
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def prof(golden_dir):
+    return np.load(os.path.join(golden_dir, "profiles.npz"))
+
+
+@pytest.fixture(scope="module")
+def dist(golden_dir):
+    return np.load(os.path.join(golden_dir, "distances.npz"))
+
+
+def pack(contigs):
+    seq = np.frombuffer(b"".join(contigs), dtype=np.uint8)
+    offsets = np.zeros(len(contigs) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(c) for c in contigs])
+    return seq, offsets
+
+
+@pytest.mark.parametrize("pattern", PATTERNS)
+@pytest.mark.parametrize("strand", STRANDS)
+def test_counts_bit_exact_vs_reference(ctx, prof, pattern, strand):
+    contigs = [bytes(c) for c in prof["contigs"]]
+    seq, offsets = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, offsets, pattern, strand)
+    assert np.array_equal(counts.astype(np.int64), prof["counts_%s_%s" % (pattern, strand)])
+    assert np.array_equal(totals.astype(np.int64), prof["totals_%s_%s" % (pattern, strand)])
+    freq = ctx.frequencies(counts, totals)
+    assert np.array_equal(freq, prof["freq_%s_%s" % (pattern, strand)])      # bit-exact float64
+
+
+@pytest.mark.parametrize("key", ["1111_both", "11_plus", "1101_minus", "11011011_both"])
+@pytest.mark.parametrize("metric", ["Eucl", "JSD", "BC"])
+def test_distances_vs_reference(ctx, dist, key, metric):
+    pattern, strand = key.split("_")
+    contigs = [bytes(c) for c in dist["contigs"]]
+    seq, offsets = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, offsets, pattern, strand)
+    want = dist["%s_%s" % (metric, key)]
+    got = ctx.pairwise(counts, totals, metric)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL, equal_nan=True)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    # frequency-input entry (the reference's own argument) and the no-symmetry path agree
+    got_f = ctx.pairwise_freq(dist["freq_" + key], metric)
+    np.testing.assert_allclose(got_f, want, rtol=RTOL, atol=ATOL, equal_nan=True)
+    got_r = ctx.pairwise(counts, totals, metric, symmetric=False)
+    np.testing.assert_allclose(got_r, want, rtol=RTOL, atol=ATOL, equal_nan=True)
+    # exact zeros where the reference has exact zeros (diagonal, duplicate record 44 == 3)
+    assert np.all(np.diag(got) == 0.0)
+    if metric in ("Eucl", "BC"):
+        assert got[3, 44] == 0.0 and got[44, 3] == 0.0
+
+
+@pytest.mark.parametrize("key", ["1111_both", "11_plus", "1101_minus", "11011011_both"])
+def test_kt_sc_vs_scipy(ctx, dist, key):
+    pattern, strand = key.split("_")
+    contigs = [bytes(c) for c in dist["contigs"]]
+    seq, offsets = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, offsets, pattern, strand)
+    kt_want, sc_want = dist["scipy_KT_" + key], dist["scipy_SC_" + key]
+    n = kt_want.shape[0]
+    kt = ctx.pairwise(counts, totals, "KT")[:n, :n]
+    sc = ctx.pairwise(counts, totals, "SC")[:n, :n]
+    mask = ~np.isnan(kt_want)
+    np.testing.assert_allclose(kt[mask], kt_want[mask], rtol=RTOL, atol=ATOL)
+    assert np.all(kt[~mask] == 0.0)        # constant record: Bio.Cluster distance 1 -> KT 0 (SciPy: NaN)
+    np.testing.assert_allclose(sc, sc_want, rtol=RTOL, atol=1e-9, equal_nan=True)
+
+
+def _random_assembly(n, seed, lo=200, hi=3000, alphabet=b"ACGT"):
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(alphabet, dtype=np.uint8)
+    return [alpha[rng.integers(0, len(alpha), size=int(rng.integers(lo, hi)))].tobytes() for _ in range(n)]
+
+
+@pytest.mark.parametrize("metric", ["Eucl", "JSD", "BC"])
+def test_vs_oracle_n300(ctx, metric):
+    from oracle import phyloligo_oracle as po
+    contigs = _random_assembly(300, 300) + [b"", b"NNNN", b"ACGTNNacgtRYacgtacgtac"]
+    contigs.append(contigs[5])
+    seq, offsets = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, offsets, "1111", "both")
+    oc, ot = po.compute_counts(contigs, "1111", "both")
+    assert np.array_equal(counts.astype(np.int64), oc) and np.array_equal(totals.astype(np.int64), ot)
+    freq = po.counts_to_frequencies(oc, ot)
+    want = po.pairwise_block(freq, metric)
+    got = ctx.pairwise(counts, totals, metric)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL, equal_nan=True)
+    # independent row blocks (the multi-GPU shard shape) reproduce the full matrix bit for bit
+    a = ctx.pairwise(counts, totals, metric, row_begin=0, row_end=130)
+    b = ctx.pairwise(counts, totals, metric, row_begin=130, row_end=len(contigs))
+    full_rect = ctx.pairwise(counts, totals, metric, symmetric=False)
+    assert np.array_equal(np.vstack([a, b]), full_rect, equal_nan=True)
+    np.testing.assert_allclose(full_rect, got, rtol=1e-13, atol=1e-15, equal_nan=True)
+    # float32 container (memmap variant): one rounding of the float64 value
+    got32 = ctx.pairwise(counts, totals, metric, dtype="float32")
+    assert got32.dtype == np.float32
+    np.testing.assert_array_equal(got32, got.astype(np.float32))
+
+
+def test_long_and_ragged_records(ctx):
+    """Records longer than one chunk (multi-workgroup counting), empty ones, very short ones."""
+    from oracle import phyloligo_oracle as po
+    rng = np.random.default_rng(9)
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    lens = [0, 1, 3, 4079, 4080, 4081, 4096, 8160, 8161, 30000, 7, 0, 123457, 2, 5000]
+    contigs = [alpha[rng.choice(5, size=n, p=[.24, .25, .25, .25, .01])].tobytes() for n in lens]
+    seq, offsets = pack(contigs)
+    for pattern, strand in [("1111", "both"), ("11011011", "both"), ("10000000000000000000000000000001", "both"),
+                            ("1111", "minus"), ("110101", "plus"), ("11111111", "both")]:
+        counts, totals = ctx.count_profiles(seq, offsets, pattern, strand)
+        oc, ot = po.compute_counts(contigs, pattern, strand)
+        assert np.array_equal(counts.astype(np.int64), oc), (pattern, strand)
+        assert np.array_equal(totals.astype(np.int64), ot), (pattern, strand)
+
+
+def test_c1_config_full(ctx, golden_dir):
+    """BASELINE config 1: 1000 x 2 kb, k=4, both strands, Eucl -- corners pinned by the reference."""
+    from phyloligo_amd import synthetic
+    g = np.load(os.path.join(golden_dir, "c1_synthetic.npz"))
+    seq, offsets = synthetic.contig_bytes(1000, 2000, seed=1001)
+    counts, totals = ctx.count_profiles(seq, offsets, 4, "both")
+    assert np.all(totals == 3997)
+    freq = ctx.frequencies(counts, totals)
+    assert np.array_equal(freq[:16], g["freq_first16"])
+    for metric in ("Eucl", "JSD", "BC"):
+        m = ctx.pairwise(counts, totals, metric)
+        np.testing.assert_allclose(m[:16, :16], g["corner_" + metric], rtol=RTOL, atol=ATOL)
+        far = m[np.ix_([0, 1, 2], [500, 777, 999])]
+        np.testing.assert_allclose(far, g["far_" + metric], rtol=RTOL, atol=ATOL)
+        assert np.array_equal(m, m.T)
