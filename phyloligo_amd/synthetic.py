@@ -26,3 +26,17 @@ def fasta_bytes(seq, offsets, width=80):
         for p in range(0, len(s), width):
             out.append(s[p:p + width] + b"\n")
     return b"".join(out)
+
+
+def contig_bytes_range(n, length, seed, lo, hi):
+    """Contigs [lo,hi) of the assembly contig_bytes(n, length, seed) without materialising the rest
+    (the generator is advanced past the first `lo` contigs draw by draw)."""
+    rng = np.random.default_rng(seed)
+    for _ in range(lo):
+        rng.integers(0, 4, size=length, dtype=np.uint8)
+    m = hi - lo
+    seq = np.empty(m * length, dtype=np.uint8)
+    for i in range(m):
+        seq[i * length:(i + 1) * length] = _ACGT[rng.integers(0, 4, size=length, dtype=np.uint8)]
+    offsets = np.arange(m + 1, dtype=np.uint64) * np.uint64(length)
+    return seq, offsets
