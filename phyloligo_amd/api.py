@@ -191,10 +191,7 @@ def fasta_index(data):
     tb = np.zeros(nrec.value, dtype=np.uint64)
     te = np.zeros(nrec.value, dtype=np.uint64)
     check(lib.po_fasta_extract(_np_ptr(buf), buf.shape[0], _np_ptr(seq), _np_ptr(offsets), _np_ptr(tb), _np_ptr(te)))
-    raw = buf.tobytes() if nrec.value < 100000 else None
-    titles = None
-    if raw is not None:
-        titles = [raw[int(b):int(e)].decode("latin-1") for b, e in zip(tb, te)]
+    titles = [buf[int(b):int(e)].tobytes().decode("latin-1") for b, e in zip(tb, te)]
     return seq, offsets, titles
 
 

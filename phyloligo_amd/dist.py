@@ -36,9 +36,20 @@ class RowBlockPlan:
         if len(set(sizes)) == 1:
             dist.all_gather_into_tensor(counts, my_counts.contiguous())
             dist.all_gather_into_tensor(totals, my_totals.contiguous())
-        else:
-            cviews = [counts[self.bounds[r]:self.bounds[r + 1]] for r in range(self.world)]
-            tviews = [totals[self.bounds[r]:self.bounds[r + 1]] for r in range(self.world)]
-            dist.all_gather(cviews, my_counts.contiguous())
-            dist.all_gather(tviews, my_totals.contiguous())
+            return counts, totals
+        # ragged last block(s): gather equal-size padded blocks, keep the valid rows (works on
+        # every backend; the padding is at most one block of the count matrix)
+        per = max(sizes)
+        pc = torch.zeros((per, dim), dtype=my_counts.dtype, device=my_counts.device)
+        pt = torch.zeros((per,), dtype=my_totals.dtype, device=my_totals.device)
+        pc[:my_counts.shape[0]] = my_counts
+        pt[:my_totals.shape[0]] = my_totals
+        gc = torch.empty((self.world * per, dim), dtype=my_counts.dtype, device=my_counts.device)
+        gt = torch.empty((self.world * per,), dtype=my_totals.dtype, device=my_totals.device)
+        dist.all_gather_into_tensor(gc, pc)
+        dist.all_gather_into_tensor(gt, pt)
+        for r in range(self.world):
+            lo, hi = self.bounds[r], self.bounds[r + 1]
+            counts[lo:hi] = gc[r * per:r * per + (hi - lo)]
+            totals[lo:hi] = gt[r * per:r * per + (hi - lo)]
         return counts, totals

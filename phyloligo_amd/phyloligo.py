@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Host-side mirror of the reference's dispatcher interface for the all-by-all distance path.
+
+Same names, argument order and error behaviour as /root/reference/phylopackage/bin/phyloligo.py:
+    compute_frequencies(...)  :980-997      compute_distances(...)  :536-553
+    get_cmd()                 :1000-1034    main()                  :1036-1068
+so a script written against the reference runs unchanged; every `--method` value executes the
+HIP kernels of libphyloligo_amd.so (there is no joblib/scoop task farm and no CPU fallback).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from . import api
+from ._lib import METRICS, STRANDS
+
+_ctx = None
+
+
+def _context():
+    global _ctx
+    if _ctx is None:
+        _ctx = api.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _ctx
+
+
+class ProfileMatrix(np.ndarray):
+    """float64[N, 4^k] frequencies exactly as compute_frequencies_joblib returns them
+    (phyloligo.py:847-877), carrying the exact integer profile they were derived from."""
+
+    def __new__(cls, freq, counts=None, totals=None, titles=None):
+        obj = np.asarray(freq, dtype=np.float64).view(cls)
+        obj.counts, obj.totals, obj.titles = counts, totals, titles
+        return obj
+
+    def __array_finalize__(self, obj):
+        if obj is None:
+            return
+        self.counts = self.totals = self.titles = None   # slices/copies are plain frequencies
+
+
+def read_fasta(genome):
+    """(seq uint8, offsets uint64[n+1], titles) of a multi-FASTA file, record order preserved."""
+    size = os.path.getsize(genome)
+    if size == 0:
+        return np.zeros(0, np.uint8), np.zeros(1, np.uint64), []
+    data = np.memmap(genome, dtype=np.uint8, mode="r")
+    try:
+        return api.fasta_index(data)
+    finally:
+        del data
+
+
+def compute_frequencies(mthdrun, large, genome, pattern, strand, distchunksize=250, threads_max=4, workdir="."):
+    """phyloligo.py:980-997.  Returns (frequencies, freq_name); freq_name is always None here
+    (no on-disk frequency container: the count matrix lives in HBM / host memory)."""
+    if mthdrun not in ("joblib", "scoop", "hip"):
+        print("Method {} is unknown".format(mthdrun), file=sys.stderr)      # :995, no exit
+        return None, None
+    if strand not in STRANDS:                                                # select_strand :146-148
+        print("Error, strand parameter of selectd_strand() should be choose from {'both', 'minus', 'plus'}",
+              file=sys.stderr)
+        sys.exit(1)
+    seq, offsets, titles = read_fasta(genome)
+    ctx = _context()
+    counts, totals = ctx.count_profiles(seq, offsets, pattern, strand)
+    freq = ctx.frequencies(counts, totals)
+    return ProfileMatrix(freq, counts, totals, titles), None
+
+
+def _row_chunk(n, itemsize, budget=1 << 30):
+    return max(128, (budget // max(1, n * itemsize)) // 128 * 128)
+
+
+def compute_distances(mthdrun, large, frequencies, freq_name, out_file, dist, threads_max=4, freqchunksize=250,
+                      workdir="."):
+    """phyloligo.py:536-553.  `--large None`: returns the float64[N,N] matrix (main writes it).
+    `--large memmap`: writes the headerless float32 row-major matrix to out_file as
+    compute_distances_memmap does (:394-427, container dtype :413) and returns None."""
+    if mthdrun not in ("joblib", "scoop", "hip"):
+        print("Error, method {} is not implemented for pairwise distances computation".format(mthdrun), file=sys.stderr)
+        return None
+    if dist not in METRICS:                                                  # :383-385
+        print("Error, unknown metric methodfor joblib: {}".format(dist), file=sys.stderr)
+        sys.exit(1)
+    if large == "h5py":
+        print("Error, --large h5py needs the h5py container, which this build does not provide", file=sys.stderr)
+        sys.exit(1)
+    ctx = _context()
+    counts = getattr(frequencies, "counts", None)
+    totals = getattr(frequencies, "totals", None)
+    n = frequencies.shape[0]
+
+    def rows(lo, hi, dtype, symmetric):
+        if counts is not None:
+            return ctx.pairwise(counts, totals, dist, lo, hi, dtype=dtype, symmetric=symmetric)
+        return ctx.pairwise_freq(np.asarray(frequencies, dtype=np.float64), dist, lo, hi, dtype=dtype,
+                                 symmetric=symmetric)
+
+    if large == "memmap":
+        out = np.memmap(out_file, dtype=np.float32, shape=(n, n), mode="w+")
+        step = _row_chunk(n, 4)
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            out[lo:hi] = rows(lo, hi, "float32", lo == 0 and hi == n)
+        out.flush()
+        del out
+        return None
+    if n * n * 8 <= (4 << 30):
+        return rows(0, n, "float64", True)
+    res = np.empty((n, n), dtype=np.float64)
+    step = _row_chunk(n, 8)
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        res[lo:hi] = rows(lo, hi, "float64", False)
+    return res
+
+
+def get_cmd(argv=None):
+    """phyloligo.py:1000-1034, option for option.  -k and -p share dest="pattern": whichever comes
+    last on the command line wins; with neither the int default 4 is used (-> "1111")."""
+    parser = argparse.ArgumentParser(prog="phyloligo.py")
+    parser.add_argument("-i", "--assembly", action="store", required=True, dest="genome",
+                        help="multifasta of the genome assembly")
+    parser.add_argument("-k", "--lgMot", action="store", dest="pattern", default=4, type=int,
+                        help="word lenght / kmer length / k [default:%(default)d]")
+    parser.add_argument("-s", "--strand", action="store", dest="strand", default="both",
+                        choices=["both", "plus", "minus"],
+                        help="strand used to compute microcomposition. [default:%(default)s]")
+    parser.add_argument("-d", "--distance", action="store", dest="dist", default="Eucl",
+                        choices=["Eucl", "JSD", "KT", "BC", "SC"],
+                        help="how to compute distance between two signatures : Eucl : Euclidean[default:%(default)s], "
+                             "JSD : Jensen-Shannon divergence, KT: Kendall's tau, BC: Bray-Curtis, SC:Spearman Correlation")
+    parser.add_argument("--freq-chunk-size", action="store", dest="freqchunksize", type=int, default=250,
+                        help="accepted for compatibility (scoop chunking; unused on the GPU)")
+    parser.add_argument("--dist-chunk-size", action="store", dest="distchunksize", type=int, default=250,
+                        help="accepted for compatibility (scoop chunking; unused on the GPU)")
+    parser.add_argument("--method", action="store", choices=["scoop", "joblib", "hip"], default="joblib",
+                        dest="mthdrun", required=True,
+                        help="kept from the reference; every value runs the MI355X HIP path")
+    parser.add_argument("--large", action="store", dest="large", choices=["None", "memmap", "h5py"], default="None",
+                        help="memmap: write the matrix as raw float32 instead of text")
+    parser.add_argument("-c", "--cpu", action="store", dest="threads_max", type=int, default=4,
+                        help="accepted for compatibility (host threads are not the compute resource)")
+    parser.add_argument("-o", "--out", action="store", dest="out_file", default="phyloligo.out",
+                        help="output file[default:%(default)s]")
+    parser.add_argument("-q", "--outfreq", action="store", dest="out_freq_file",
+                        help="kmer frequencies output file")
+    parser.add_argument("-w", "--workdir", action="store", dest="workdir", default=".", help="working directory")
+    parser.add_argument("-p", "--pattern", action="store", dest="pattern", default="1111",
+                        help="spaced-word pattern string, only containing 1s and 0s, i.e. '100101001', default='1111'")
+    params = parser.parse_args(argv)
+    params.workdir = os.path.abspath(params.workdir)
+    return params
+
+
+def main(argv=None):
+    params = get_cmd(argv)
+    if type(params.pattern) == int:                      # :1040-1041
+        params.pattern = str("1") * params.pattern
+    print("Using pattern {}".format(params.pattern))
+    if not os.path.isdir(params.workdir):
+        os.makedirs(params.workdir)
+    print("Computing frequencies")
+    frequencies, freq_name = compute_frequencies(params.mthdrun, params.large, params.genome, params.pattern,
+                                                 params.strand, params.distchunksize, params.threads_max,
+                                                 params.workdir)
+    print("Computing Pairwise distances")
+    res = compute_distances(params.mthdrun, params.large, frequencies, freq_name, params.out_file, params.dist,
+                            params.threads_max, params.freqchunksize, params.workdir)
+    if params.out_freq_file:
+        print("Writing frequency matrix")
+        api.write_mat_text(params.out_freq_file, np.asarray(frequencies))
+    if not (params.mthdrun in ("joblib", "hip") and params.large != "None"):
+        print("Writing distance matrix")
+        api.write_mat_text(params.out_file, res)
+    return 0
+
+
+if __name__ == "__main__":
+    main()
+    sys.exit(0)

@@ -1,0 +1,124 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports what include/*.h
+declares, host formats (FASTA ingest, .mat text) match the reference's, CLI resolution matches
+the reference's argparse, and compute calls fail loudly without a GPU.  No compute on CPU."""
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+import phyloligo_amd as pa
+from phyloligo_amd import _lib, phyloligo as P
+from oracle import phyloligo_oracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "phyloligo_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(po_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libphyloligo_amd.so does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), "ctypes table and header out of step"
+    assert lib.po_abi_version() == 1
+    assert b"gfx950" in lib.po_version()
+
+
+def test_pattern_info_and_errors():
+    assert pa.pattern_info("1111") == (4, 4, 256)
+    assert pa.pattern_info(4) == (4, 4, 256)
+    assert pa.pattern_info("11011011") == (8, 6, 4096)
+    assert pa.pattern_info("1" + "0" * 30 + "1") == (32, 2, 16)
+    for bad in ("", "000", "12", "1" * 9, "1" + "0" * 32 + "1"):
+        with pytest.raises(pa.PhyloligoError):
+            pa.pattern_info(bad)
+
+
+def test_no_cpu_fallback():
+    if pa.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(pa.PhyloligoError) as e:
+        pa.Context(0)
+    assert e.value.status == _lib.PO_ENODEV
+    with pytest.raises(pa.PhyloligoError):
+        P.compute_frequencies("joblib", "None", __file__, "1111", "both")
+
+
+FASTA_CASES = [
+    b">a desc\nACGT\nAC GT\r\n\n>b\n>c\nNN\nacgt  \n",
+    b"\n\n>only\nACGTACGT",
+    b">x\n\n\nAC\tGT \t\nTT\n>y  trailing  \nGG\x0b\n",
+    b">e1\n>e2\n>e3\n",
+    b"",
+    b">last\nAC\r\nGT\r\n",
+]
+
+
+@pytest.mark.parametrize("data", FASTA_CASES)
+def test_fasta_index_matches_biopython_semantics(data):
+    titles, seqs = po.parse_fasta(data)
+    seq, offsets, got_titles = pa.fasta_index(data)
+    assert got_titles == titles
+    assert len(offsets) == len(seqs) + 1
+    for i, s in enumerate(seqs):
+        assert seq[int(offsets[i]):int(offsets[i + 1])].tobytes() == s
+
+
+def test_fasta_rejects_leading_text():
+    with pytest.raises(pa.PhyloligoError):
+        pa.fasta_index(b"ACGT\n>a\nAC\n")
+
+
+def test_fasta_wrapped_synthetic_roundtrip():
+    from phyloligo_amd import synthetic
+    seq, offsets = synthetic.contig_bytes(37, 333, seed=5)
+    data = synthetic.fasta_bytes(seq, offsets)
+    seq2, off2, titles = pa.fasta_index(data)
+    assert np.array_equal(seq, seq2) and np.array_equal(offsets, off2)
+    assert titles[0] == "c0000000" and titles[-1] == "c0000036"
+    assert data == po.fasta_bytes(po.synthetic_contigs(37, 333, seed=5))
+
+
+def test_mat_text_is_numpy_savetxt(tmp_path, golden_dir):
+    g = np.load(os.path.join(golden_dir, "distances.npz"))
+    m = g["JSD_1111_both"]
+    path = tmp_path / "a.mat"
+    pa.write_mat_text(path, m)
+    assert path.read_bytes() == g["matbytes_JSD_1111_both"].tobytes()     # the reference's own bytes
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.standard_normal(500) * 10.0 ** rng.integers(-300, 300, 500),
+                        [0.0, -0.0, np.nan, np.inf, -np.inf, 1e-310, 5e-324, 1.7976931348623157e308]]).reshape(-1, 4)
+    pa.write_mat_text(path, x)
+    buf = io.BytesIO()
+    np.savetxt(buf, x, delimiter="\t")
+    assert path.read_bytes() == buf.getvalue()
+    pa.write_mat_text(path, x[:2], append=True)
+    assert path.read_bytes() == buf.getvalue() + buf.getvalue()[:len(buf.getvalue().split(b"\n")[0]) * 0 + sum(len(l) + 1 for l in buf.getvalue().split(b"\n")[:2])]
+
+
+def test_cli_resolution_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "cli.npz"))
+    for k in z.files:
+        argv = str(z[k][0]).split()
+        p = P.get_cmd(argv)
+        pat = p.pattern
+        if type(pat) == int:
+            pat = "1" * pat
+        assert [pat, p.strand, p.dist, p.out_file, p.large, str(p.threads_max)] == [str(x) for x in z[k][1:]], k
+    with pytest.raises(SystemExit) as e:          # --method is required, argparse exits 2
+        P.get_cmd(["-i", "x.fa"])
+    assert e.value.code == 2
+    with pytest.raises(SystemExit):
+        P.get_cmd(["-i", "x.fa", "--method", "joblib", "-d", "XX"])
+
+
+def test_synthetic_generators_agree():
+    from phyloligo_amd import synthetic
+    seq, offsets = synthetic.contig_bytes(20, 100, seed=5)
+    part, _ = synthetic.contig_bytes_range(20, 100, 5, 7, 13)
+    assert np.array_equal(seq[700:1300], part)
+    assert b"".join(po.synthetic_contigs(20, 100, seed=5)) == seq.tobytes()
