@@ -279,7 +279,7 @@ static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
     int rc = po_buf_reserve(ctx, &ctx->ws_rowstat, 4 * npad * sizeof(double));
     if (rc) return rc;
     if (metric != PO_KT) {
-        rc = po_buf_reserve(ctx, &ctx->ws_freq, (uint64_t)dim * npad * sizeof(double));
+        rc = po_buf_reserve(ctx, &ctx->ws_freq, po_round_up(dim, 8) * npad * sizeof(double));
         if (rc) return rc;
     } else {
         rc = po_buf_reserve(ctx, &ctx->ws_aux, n * (uint64_t)dim * sizeof(uint32_t));

@@ -156,6 +156,8 @@ __global__ __launch_bounds__(kThreads) void kt_tile_kernel(const uint32_t* __res
 int po_launch_ranks(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint64_t n, uint32_t dim,
                     uint64_t npad, double* d_rt, uint32_t* d_lessrank, double* d_rowstat) {
     if (n == 0) return PO_OK;
+    if (d_rt && (dim & 7u))   // operand rows are padded to a multiple of 8 words
+        PO_HIP(hipMemsetAsync(d_rt + (uint64_t)dim * npad, 0, (po_round_up(dim, 8) - dim) * npad * sizeof(double), ctx->stream));
     if (d_rt && npad > n) {
         hipLaunchKernelGGL(zero_pad_kernel, dim3(256), dim3(kThreads), 0, ctx->stream, d_rt, n, dim, npad);
         PO_CHECK_LAUNCH("zero_pad_kernel");

@@ -2,7 +2,7 @@
 // layouts stage 2 reads, plus the per-row terms the tile kernels fold into their epilogues.
 //
 // Working layout of stage 2:  Ft[d][npad] = counts[n][d] / totals[n]  (float64, transposed so a
-// tile's rows are contiguous along n; columns n..npad-1 are zero).  The division is the same
+// tile's rows are contiguous along n; columns n..npad-1 and rows dim..roundup(dim,8)-1 are zero).  The division is the same
 // correctly-rounded float64 division the reference performs (int/int true division, :656).
 #include "po_internal.h"
 
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void prep_transpose_kernel(const uint32_t* __r
     }
     __syncthreads();
     for (uint32_t r = ty; r < 64; r += 4) {                        // r: word within tile, tx: record
-        if (d0 + r < dim && n0 + tx < npad) ft[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r];
+        if (d0 + r < ((dim + 7u) & ~7u) && n0 + tx < npad) ft[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r];
     }
 }
 
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void prep_transpose_freq_kernel(const double* 
     }
     __syncthreads();
     for (uint32_t r = ty; r < 64; r += 4) {
-        if (d0 + r < dim && n0 + tx < npad) ft[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r];
+        if (d0 + r < ((dim + 7u) & ~7u) && n0 + tx < npad) ft[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r];
     }
 }
 

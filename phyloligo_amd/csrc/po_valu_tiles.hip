@@ -22,6 +22,7 @@
 #include "po_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -54,12 +55,176 @@ template <> __device__ __forceinline__ void store_out<float>(void* out, uint64_t
     static_cast<float*>(out)[idx] = (float)v;
 }
 
-template <int METRIC, typename OUT>
+struct JsdConsts {
+    uint32_t tcopy;   // LDS byte address of this lane's table copy
+    uint32_t k3ff;    // 0x3ff00000 in a VGPR (VOP3 takes no literal on gfx9)
+    double c4;        // -1/4 in a VGPR pair
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef const __attribute__((address_space(1))) unsigned char glb_byte;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)((const lds_byte*)p); }
+__device__ __forceinline__ double2 lds_read_d2(uint32_t addr) {
+    return *((const __attribute__((address_space(3))) double2*)(uintptr_t)addr);
+}
+// 64 lanes x 16 B straight from global memory into 1 KiB of LDS at `lds_base` (wave uniform)
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((glb_byte*)gptr, (lds_byte*)lds_base, 16, 0, 0);
+}
+#else
+__device__ __forceinline__ uint32_t lds_addr(const void*) { return 0; }
+__device__ __forceinline__ double2 lds_read_d2(uint32_t) { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ void glds16(const void*, void*) {}
+#endif
+
+constexpr int GS = 2;              // pairs per pipeline group
+constexpr int NG = 64 / GS;        // groups per word
+
+// fragments of one staged word: 8 records of the row block (broadcast), 8 of the column block.
+// HEAD = what the first 8 groups of the word need (a[0..7] come in pairs: a[0..1], b[0..1]);
+// REST = everything else.
+template <bool HEAD, bool REST>
+__device__ __forceinline__ void load_frag(const double* s, int k, uint32_t tx, uint32_t ty, double (&a)[8], double (&b)[8]) {
+    const double* sa = s + k * (TM + TN) + ty * 8;
+    const double* sb = s + k * (TM + TN) + TM + tx * 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if ((q == 0) ? HEAD : REST) {
+            const double2 v = *reinterpret_cast<const double2*>(sa + 2 * q);
+            a[2 * q] = v.x; a[2 * q + 1] = v.y;
+            const double2 u = *reinterpret_cast<const double2*>(sb + 32 * q);
+            b[2 * q] = u.x; b[2 * q + 1] = u.y;
+        }
+    }
+}
+
+// group G of a word: pairs (ia = G%8, ib = GS*(G/8) .. +GS-1).  Sum, table address, table read.
+template <int G>
+__device__ __forceinline__ void jsd_issue(const JsdConsts& C, const double (&a)[8], const double (&b)[8],
+                                          double (&psum)[GS], double2 (&pte)[GS]) {
+    constexpr int ia = G & 7, ib0 = (G >> 3) * GS;
+#pragma unroll
+    for (int e = 0; e < GS; ++e) {
+        const double sum = a[ia] + b[ib0 + e];
+        uint32_t toff;
+        asm("v_bfe_u32 %0, %1, 13, 7\n\tv_lshl_or_b32 %0, %0, 8, %2" : "=&v"(toff) : "v"(__double2hiint(sum)), "v"(C.tcopy));
+        psum[e] = sum;
+        pte[e] = lds_read_d2(toff);
+    }
+}
+
+template <int VAR, int G>
+__device__ __forceinline__ void jsd_eval(const JsdConsts& C, const double (&psum)[GS], const double2 (&pte)[GS],
+                                         double (&acc)[8][8]) {
+    constexpr int ia = G & 7, ib0 = (G >> 3) * GS;
+    const double c3 = 1.0 / 3.0;
+#pragma unroll
+    for (int e = 0; e < GS; ++e) {
+        const double sum = psum[e];
+        const double2 te = pte[e];
+        double m, ef;
+        if (VAR == 0) {          // integer field surgery on the bit pattern
+            const uint32_t hi = (uint32_t)__double2hiint(sum);
+            uint32_t mhi;
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(mhi) : "v"(hi), "s"(0x000FFFFFu), "v"(C.k3ff));
+            m = __hiloint2double((int)mhi, __double2loint(sum));
+            ef = (double)__builtin_amdgcn_ubfe(hi, 20, 11);
+        } else {                 // hardware frexp
+            m = __builtin_amdgcn_frexp_mant(sum);
+            ef = (double)__builtin_amdgcn_frexp_exp(sum);
+        }
+        double r, q;
+        asm("v_fma_f64 %0, %1, %2, -1.0" : "=v"(r) : "v"(m), "v"(te.x));
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "v"(r), "v"(C.c4), "s"(c3));
+        q = fma(r, q, -0.5);
+        q = fma(r, q, 1.0);
+        const double big = fma(ef, LN2, te.y);
+        const double ln_s = fma(r, q, big);
+        acc[ia][ib0 + e] = fma(sum, ln_s, acc[ia][ib0 + e]);
+    }
+}
+
+__device__ __forceinline__ void jsd_issue_ab(const JsdConsts& C, double a, const double* b, double (&psum)[GS], double2 (&pte)[GS]) {
+#pragma unroll
+    for (int e = 0; e < GS; ++e) {
+        const double sum = a + b[e];
+        uint32_t toff;
+        asm("v_bfe_u32 %0, %1, 13, 7\n\tv_lshl_or_b32 %0, %0, 8, %2" : "=&v"(toff) : "v"(__double2hiint(sum)), "v"(C.tcopy));
+        psum[e] = sum;
+        pte[e] = lds_read_d2(toff);
+    }
+}
+
+template <int VAR>
+__device__ __forceinline__ void jsd_eval_ab(const JsdConsts& C, const double (&psum)[GS], const double2 (&pte)[GS], double* acc) {
+    const double c3 = 1.0 / 3.0;
+#pragma unroll
+    for (int e = 0; e < GS; ++e) {
+        const double sum = psum[e];
+        const double2 te = pte[e];
+        double m, ef;
+        if (VAR == 0) {
+            const uint32_t hi = (uint32_t)__double2hiint(sum);
+            uint32_t mhi;
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(mhi) : "v"(hi), "s"(0x000FFFFFu), "v"(C.k3ff));
+            m = __hiloint2double((int)mhi, __double2loint(sum));
+            ef = (double)__builtin_amdgcn_ubfe(hi, 20, 11);
+        } else {
+            m = __builtin_amdgcn_frexp_mant(sum);
+            ef = (double)__builtin_amdgcn_frexp_exp(sum);
+        }
+        double r, q;
+        asm("v_fma_f64 %0, %1, %2, -1.0" : "=v"(r) : "v"(m), "v"(te.x));
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "v"(r), "v"(C.c4), "s"(c3));
+        q = fma(r, q, -0.5);
+        q = fma(r, q, 1.0);
+        const double big = fma(ef, LN2, te.y);
+        const double ln_s = fma(r, q, big);
+        acc[e] = fma(sum, ln_s, acc[e]);
+    }
+}
+
+// Groups G..NG-1 of one word: while group G is evaluated from buffer G%2, group G+1 (or group 0 of
+// the next word) is in flight in the other buffer.
+template <int VAR, bool NEXT, int G>
+__device__ __forceinline__ void jsd_groups(const JsdConsts& C, const double* s, int k, uint32_t tx, uint32_t ty,
+                                           const double (&a)[8], const double (&b)[8], double (&an)[8], double (&bn)[8],
+                                           double (&p0)[GS], double2 (&t0)[GS], double (&p1)[GS], double2 (&t1)[GS],
+                                           double (&acc)[8][8]) {
+    if constexpr (G == NG - 8) {
+        if (NEXT) load_frag<true, false>(s, k + 1, tx, ty, an, bn);
+    }
+    if constexpr (G + 1 < NG) {
+        if constexpr ((G & 1) == 0) jsd_issue<G + 1>(C, a, b, p1, t1); else jsd_issue<G + 1>(C, a, b, p0, t0);
+    } else if (NEXT) {
+        if constexpr ((G & 1) == 0) jsd_issue<0>(C, an, bn, p1, t1); else jsd_issue<0>(C, an, bn, p0, t0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((G & 1) == 0) jsd_eval<VAR, G>(C, p0, t0, acc); else jsd_eval<VAR, G>(C, p1, t1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G + 1 < NG) jsd_groups<VAR, NEXT, G + 1>(C, s, k, tx, ty, a, b, an, bn, p0, t0, p1, t1, acc);
+}
+
+// One word (64 pairs) at staged position k.  On entry the HEAD fragments of the word are loaded and
+// its group 0 is in flight in (p0,t0); on exit, when NEXT, the same holds for word k+1 (an, bn).
+// NG is even, so the buffer roles are the same for every word.
+template <int VAR, bool NEXT>
+__device__ __forceinline__ void jsd_word(const JsdConsts& C, const double* s, int k, uint32_t tx, uint32_t ty,
+                                         double (&a)[8], double (&b)[8], double (&an)[8], double (&bn)[8],
+                                         double (&p0)[GS], double2 (&t0)[GS], double (&p1)[GS], double2 (&t1)[GS],
+                                         double (&acc)[8][8]) {
+    load_frag<false, true>(s, k, tx, ty, a, b);
+    jsd_groups<VAR, NEXT, 0>(C, s, k, tx, ty, a, b, an, bn, p0, t0, p1, t1, acc);
+}
+
+template <int METRIC, typename OUT, int VAR>
 __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, const double2* __restrict__ logtab,
                                                                 uint32_t tiles_n, uint32_t tile_row0) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double* stage = reinterpret_cast<double*>(smem);                    // [2][KC][TM+TN]
-    unsigned char* tab = smem + 2 * kStageDoubles * sizeof(double);     // JSD only
+    // the log table comes first so that a lane's lookup address is just (interval << 8 | copy)
+    unsigned char* tab = smem;                                          // JSD only, kTabBytes
+    double* stage = reinterpret_cast<double*>(smem + (METRIC == PO_JSD ? kTabBytes : 0));   // [2][KC][TM+TN]
 
     const uint32_t t = threadIdx.x;
     const uint32_t tx = t & 15, ty = t >> 4;
@@ -86,79 +251,66 @@ __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, 
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
 
-    // staging role: lane loads 4 consecutive records of word (k0 + sk) for A and for B
-    const uint32_t sk = t >> 5, sc = (t & 31) * 4;
-    const double* gA = A.ft + i0 + sc;
-    const double* gB = A.ft + j0 + sc;
-    double2 ra0, ra1, rb0, rb1;
-    auto gload = [&](uint32_t k0) {
-        const uint32_t k = k0 + sk;
-        if (k < A.dim) {
-            const double* pa = gA + (uint64_t)k * A.npad;
-            const double* pb = gB + (uint64_t)k * A.npad;
-            ra0 = *reinterpret_cast<const double2*>(pa);
-            ra1 = *reinterpret_cast<const double2*>(pa + 2);
-            rb0 = *reinterpret_cast<const double2*>(pb);
-            rb1 = *reinterpret_cast<const double2*>(pb + 2);
-        } else {
-            ra0 = ra1 = rb0 = rb1 = make_double2(0.0, 0.0);
+    // staging: wave w copies words 2w, 2w+1 of the step -- 64 lanes x 16 B per instruction, straight
+    // from HBM/L2 into the lane-linear LDS rows (no VGPR round trip)
+    const uint32_t lane = t & 63, wave = t >> 6;
+    auto gstage = [&](uint32_t k0, uint32_t buf) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t k = wave * 2 + r;
+            const double* row = A.ft + (uint64_t)(k0 + k) * A.npad + lane * 2;
+            double* dst = stage + buf * kStageDoubles + k * (TM + TN);
+            glds16(row + i0, dst);
+            glds16(row + j0, dst + TM);
         }
     };
-    auto sstore = [&](uint32_t buf) {
-        double* s = stage + buf * kStageDoubles + sk * (TM + TN);
-        *reinterpret_cast<double2*>(s + sc) = ra0;
-        *reinterpret_cast<double2*>(s + sc + 2) = ra1;
-        *reinterpret_cast<double2*>(s + TM + sc) = rb0;
-        *reinterpret_cast<double2*>(s + TM + sc + 2) = rb1;
-    };
-
-    gload(0);
-    sstore(0);
+    gstage(0, 0);
     __syncthreads();
 
-    const uint32_t tcopy = tx * 16;                                      // this lane's table copy
+    // this lane's copy of the table as a raw LDS byte address: lookup = (interval << 8) | tcopy
+    JsdConsts C;
+    C.tcopy = lds_addr(tab) + tx * 16;
+    {
+        uint32_t c4lo, c4hi;
+        asm volatile("v_mov_b32 %0, 0x3ff00000" : "=v"(C.k3ff));
+        asm volatile("v_mov_b32 %0, 0" : "=v"(c4lo));
+        asm volatile("v_mov_b32 %0, 0xbfd00000" : "=v"(c4hi));
+        C.c4 = __hiloint2double((int)c4hi, (int)c4lo);                  // -1/4 held in a VGPR pair
+    }
+
     uint32_t cur = 0;
     for (uint32_t k0 = 0; k0 < A.dim; k0 += KC) {
         const bool more = k0 + KC < A.dim;
-        if (more) gload(k0 + KC);
+        if (more) gstage(k0 + KC, cur ^ 1);
         const double* s = stage + cur * kStageDoubles;
+        if (METRIC == PO_JSD) {
 #pragma unroll 2
-        for (int k = 0; k < KC; ++k) {
-            const double* sa = s + k * (TM + TN) + ty * 8;
-            const double* sb = s + k * (TM + TN) + TM + tx * 2;
-            double a[8], b[8];
+            for (int k = 0; k < KC; ++k) {
+                double a[8], b[8];
+                load_frag<true, true>(s, k, tx, ty, a, b);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double2 v = *reinterpret_cast<const double2*>(sa + 2 * q);
-                a[2 * q] = v.x; a[2 * q + 1] = v.y;
-                const double2 u = *reinterpret_cast<const double2*>(sb + 32 * q);
-                b[2 * q] = u.x; b[2 * q + 1] = u.y;
-            }
+                for (int ia = 0; ia < 8; ++ia) {
 #pragma unroll
-            for (int ia = 0; ia < 8; ++ia) {
-#pragma unroll
-                for (int ib = 0; ib < 8; ++ib) {
-                    if (METRIC == PO_JSD) {
-                        const double sum = a[ia] + b[ib];
-                        const uint32_t hi = (uint32_t)__double2hiint(sum);
-                        const uint32_t lo = (uint32_t)__double2loint(sum);
-                        const double2 te = *reinterpret_cast<const double2*>(tab + (((hi >> 5) & 0x7F00u) | tcopy));
-                        const double m = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), (int)lo);
-                        const double X = __hiloint2double((int)(((hi >> 11) & 0x000FFE00u) | 0x40A00000u), 0);
-                        const double r = fma(m, te.x, -1.0);
-                        double q = fma(r, -0.25, 1.0 / 3.0);
-                        q = fma(r, q, -0.5);
-                        const double big = fma(X, LN2, te.y) + r;
-                        const double ln_s = fma(r * r, q, big);
-                        acc[ia][ib] = fma(sum, ln_s, acc[ia][ib]);
-                    } else {  // PO_BC
-                        acc[ia][ib] += fabs(a[ia] - b[ib]);
+                    for (int ib = 0; ib < 8; ib += GS) {
+                        double psum[GS];
+                        double2 pte[GS];
+                        jsd_issue_ab(C, a[ia], &b[ib], psum, pte);
+                        jsd_eval_ab<VAR>(C, psum, pte, &acc[ia][ib]);
                     }
                 }
             }
+        } else {  // PO_BC
+#pragma unroll 2
+            for (int k = 0; k < KC; ++k) {
+                double a[8], b[8];
+                load_frag<true, true>(s, k, tx, ty, a, b);
+#pragma unroll
+                for (int ia = 0; ia < 8; ++ia)
+#pragma unroll
+                    for (int ib = 0; ib < 8; ++ib) acc[ia][ib] += fabs(a[ia] - b[ib]);
+            }
         }
-        if (more) sstore(cur ^ 1);
-        __syncthreads();
+        __syncthreads();      // also drains this wave's in-flight LDS-DMA (vmcnt) before the buffers swap
         cur ^= 1;
     }
 
@@ -196,7 +348,7 @@ __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, 
     }
 }
 
-template <int METRIC>
+template <int METRIC, int VAR>
 int launch_metric(po_ctx* ctx, const po_tile_args& a, uint64_t* tiles) {
     const uint32_t T = (uint32_t)((a.n + TN - 1) / TN);
     uint64_t nblocks;
@@ -212,13 +364,13 @@ int launch_metric(po_ctx* ctx, const po_tile_args& a, uint64_t* tiles) {
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
     const size_t shmem = 2 * kStageDoubles * sizeof(double) + (METRIC == PO_JSD ? kTabBytes : 0);
-    const double2* tab = static_cast<const double2*>(ctx->ws_logtab.p);
+    const double2* tab = reinterpret_cast<const double2*>(static_cast<const unsigned char*>(ctx->ws_logtab.p) + VAR * kTabBytes);
     if (a.out_f32) {
-        auto k = valu_tile_kernel<METRIC, float>;
+        auto k = valu_tile_kernel<METRIC, float, VAR>;
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, tab, T, tile_row0);
     } else {
-        auto k = valu_tile_kernel<METRIC, double>;
+        auto k = valu_tile_kernel<METRIC, double, VAR>;
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, tab, T, tile_row0);
     }
@@ -228,24 +380,28 @@ int launch_metric(po_ctx* ctx, const po_tile_args& a, uint64_t* tiles) {
 
 }  // namespace
 
-// {invc, logc - 3071 ln2} for the 128 mantissa intervals, each entry replicated 16x so that
-// copy c of entry j sits at byte j*256 + c*16 (banks 4c..4c+3).
+// Log tables for the 128 mantissa intervals, each entry replicated 16x so that copy c of entry j
+// sits at byte j*256 + c*16 (banks 4c..4c+3).  Two layouts, one per reduction variant:
+//   0: s = 2^(eb-1023) m, m in [1,2):  {invc,   -ln(invc) - 1023 ln2},  ef = (double)eb
+//   1: s = 2^e m,         m in [.5,1): {2 invc, -ln(invc) - ln2},       ef = (double)e
 int po_logtab_init(po_ctx* ctx) {
     if (ctx->logtab_ready) return PO_OK;
-    int rc = po_buf_reserve(ctx, &ctx->ws_logtab, kTabBytes);
+    int rc = po_buf_reserve(ctx, &ctx->ws_logtab, 2 * kTabBytes);
     if (rc) return rc;
-    static double host_tab[kTabEntries * 16 * 2];
+    static double host_tab[2][kTabEntries * 16 * 2];
     const long double ln2 = 0.693147180559945309417232121458176568L;
     for (int j = 0; j < kTabEntries; ++j) {
         const double c = 1.0 + (j + 0.5) / kTabEntries;
         const double invc = 1.0 / c;
-        const long double logc = -logl((long double)invc) - 3071.0L * ln2;
+        const long double logc = -logl((long double)invc);
         for (int r = 0; r < 16; ++r) {
-            host_tab[(j * 16 + r) * 2 + 0] = invc;
-            host_tab[(j * 16 + r) * 2 + 1] = (double)logc;
+            host_tab[0][(j * 16 + r) * 2 + 0] = invc;
+            host_tab[0][(j * 16 + r) * 2 + 1] = (double)(logc - 1023.0L * ln2);
+            host_tab[1][(j * 16 + r) * 2 + 0] = 2.0 * invc;
+            host_tab[1][(j * 16 + r) * 2 + 1] = (double)(logc - ln2);
         }
     }
-    PO_HIP(hipMemcpyAsync(ctx->ws_logtab.p, host_tab, kTabBytes, hipMemcpyHostToDevice, ctx->stream));
+    PO_HIP(hipMemcpyAsync(ctx->ws_logtab.p, host_tab, 2 * kTabBytes, hipMemcpyHostToDevice, ctx->stream));
     PO_HIP(hipStreamSynchronize(ctx->stream));
     ctx->logtab_ready = true;
     return PO_OK;
@@ -255,9 +411,11 @@ int po_launch_valu_tiles(po_ctx* ctx, int metric, const po_tile_args& a, uint64_
     if (metric == PO_JSD) {
         int rc = po_logtab_init(ctx);
         if (rc) return rc;
-        return launch_metric<PO_JSD>(ctx, a, tiles);
+        static const int variant = getenv("PO_JSD_VARIANT") ? atoi(getenv("PO_JSD_VARIANT")) : 0;
+        if (variant == 1) return launch_metric<PO_JSD, 1>(ctx, a, tiles);
+        return launch_metric<PO_JSD, 0>(ctx, a, tiles);
     }
-    if (metric == PO_BC) return launch_metric<PO_BC>(ctx, a, tiles);
+    if (metric == PO_BC) return launch_metric<PO_BC, 0>(ctx, a, tiles);
     po_set_error("po_launch_valu_tiles: metric %d is not an elementwise-reduction metric", metric);
     return PO_EINVAL;
 }
