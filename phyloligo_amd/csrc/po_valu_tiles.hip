@@ -288,15 +288,16 @@ __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, 
             for (int k = 0; k < KC; ++k) {
                 double a[8], b[8];
                 load_frag<true, true>(s, k, tx, ty, a, b);
+                // one-deep software pipeline over the 32 groups of the word: the table reads of
+                // group g+1 are issued before group g is evaluated
+                double psum[2][GS];
+                double2 pte[2][GS];
+                jsd_issue_ab(C, a[0], &b[0], psum[0], pte[0]);
 #pragma unroll
-                for (int ia = 0; ia < 8; ++ia) {
-#pragma unroll
-                    for (int ib = 0; ib < 8; ib += GS) {
-                        double psum[GS];
-                        double2 pte[GS];
-                        jsd_issue_ab(C, a[ia], &b[ib], psum, pte);
-                        jsd_eval_ab<VAR>(C, psum, pte, &acc[ia][ib]);
-                    }
+                for (int g = 0; g < NG; ++g) {
+                    const int gn = g + 1;
+                    if (gn < NG) jsd_issue_ab(C, a[gn >> 2], &b[(gn & 3) * GS], psum[gn & 1], pte[gn & 1]);
+                    jsd_eval_ab<VAR>(C, psum[g & 1], pte[g & 1], &acc[g >> 2][(g & 3) * GS]);
                 }
             }
         } else {  // PO_BC
