@@ -17,6 +17,7 @@ STRANDS = {"both": 0, "plus": 1, "minus": 2}
 METRICS = {"Eucl": 0, "JSD": 1, "KT": 2, "BC": 3, "SC": 4}
 PO_F64, PO_F32 = 0, 1
 PO_FLAG_NO_SYMMETRY = 1
+PO_FLAG_NO_TABLE_PATH = 2
 
 
 class PoStats(ctypes.Structure):

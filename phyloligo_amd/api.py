@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import METRICS, STRANDS, PO_F32, PO_F64, PO_FLAG_NO_SYMMETRY, PoStats, check
+from ._lib import METRICS, STRANDS, PO_F32, PO_F64, PO_FLAG_NO_SYMMETRY, PO_FLAG_NO_TABLE_PATH, PoStats, check
 
 
 def normalise_pattern(pattern):
@@ -123,16 +123,19 @@ class Context:
         check(self._lib.po_pairwise_reserve(self._h, n, dim, METRICS[metric]))
 
     def pairwise(self, counts, totals, metric="Eucl", row_begin=0, row_end=None, dtype="float64", symmetric=True,
-                 out=None, want_stats=False):
-        """Rows [row_begin,row_end) x all columns of the distance matrix from integer profiles."""
-        return self._pairwise(counts, totals, None, metric, row_begin, row_end, dtype, symmetric, out, want_stats)
+                 out=None, want_stats=False, table_path=True):
+        """Rows [row_begin,row_end) x all columns of the distance matrix from integer profiles.
+        table_path=False forces the general JSD kernel even for record blocks with equal totals."""
+        return self._pairwise(counts, totals, None, metric, row_begin, row_end, dtype, symmetric, out, want_stats,
+                              0 if table_path else PO_FLAG_NO_TABLE_PATH)
 
     def pairwise_freq(self, freq, metric="Eucl", row_begin=0, row_end=None, dtype="float64", symmetric=True,
                       out=None, want_stats=False):
         """The same from a float64 frequency matrix (the reference's `frequencies` argument)."""
         return self._pairwise(None, None, freq, metric, row_begin, row_end, dtype, symmetric, out, want_stats)
 
-    def _pairwise(self, counts, totals, freq, metric, row_begin, row_end, dtype, symmetric, out, want_stats):
+    def _pairwise(self, counts, totals, freq, metric, row_begin, row_end, dtype, symmetric, out, want_stats,
+                  extra_flags=0):
         if metric not in METRICS:
             raise _lib.PhyloligoError(_lib.PO_EINVAL, "unknown metric %r" % (metric,))
         src = freq if freq is not None else counts
@@ -141,7 +144,7 @@ class Context:
         rows = max(0, row_end - row_begin)
         f32 = str(dtype) in ("float32", "torch.float32", "f32")
         code = PO_F32 if f32 else PO_F64
-        flags = 0 if symmetric else PO_FLAG_NO_SYMMETRY
+        flags = (0 if symmetric else PO_FLAG_NO_SYMMETRY) | extra_flags
         stats = PoStats()
         sp = ctypes.byref(stats) if want_stats else None
         if _is_torch(src):

@@ -288,6 +288,8 @@ static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
     if (metric == PO_JSD) {
         rc = po_logtab_init(ctx);
         if (rc) return rc;
+        rc = po_buf_reserve(ctx, &ctx->ws_aux, po_jsd_lut_workspace(n, dim));
+        if (rc) return rc;
     }
     return PO_OK;
 }
@@ -359,8 +361,21 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     uint64_t tiles = 0;
     uint32_t kid = 0;
     switch (metric) {
-        case PO_JSD: rc = po_launch_valu_tiles(ctx, PO_JSD, a, &tiles); kid = PO_KERNEL_VALU_JSD; break;
-        case PO_BC: rc = po_launch_valu_tiles(ctx, PO_BC, a, &tiles); kid = PO_KERNEL_VALU_BC; break;
+        case PO_JSD: {
+            // record blocks with one common word total go through the integer-sum table kernel, the rest
+            // through the general float64 kernel; each launch skips the other's tiles (decided on device)
+            const unsigned long long* cls = nullptr;
+            if (d_counts && !(flags & PO_FLAG_NO_TABLE_PATH)) {
+                rc = po_launch_jsd_lut_prep(ctx, d_counts, d_totals, n, dim, npad, ctx->ws_aux.p, &cls);
+                if (rc) return rc;
+                rc = po_launch_jsd_lut_tiles(ctx, a, ctx->ws_aux.p, &tiles);
+                if (rc) return rc;
+            }
+            rc = po_launch_valu_tiles(ctx, PO_JSD, a, cls, &tiles);
+            kid = cls ? PO_KERNEL_LUT_JSD : PO_KERNEL_VALU_JSD;
+            break;
+        }
+        case PO_BC: rc = po_launch_valu_tiles(ctx, PO_BC, a, nullptr, &tiles); kid = PO_KERNEL_VALU_BC; break;
         case PO_EUCL: rc = po_launch_gram_f64(ctx, PO_EUCL, a, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
         case PO_SC: rc = po_launch_gram_f64(ctx, PO_SC, a, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
         case PO_KT: rc = po_launch_kt(ctx, lessrank, n, dim, a, &tiles); kid = PO_KERNEL_VALU_KT; break;

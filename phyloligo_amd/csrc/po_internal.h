@@ -104,7 +104,13 @@ struct po_tile_args {
     int out_f32;
     int symmetric;          // 1: only tiles on/above the diagonal are computed, mirrored on store
 };
-int po_launch_valu_tiles(po_ctx* ctx, int metric, const po_tile_args& a, uint64_t* tiles);
+// cls (may be NULL): per 128-record block, the common word total if the equal-total table path owns
+// the tiles of that class (po_jsd_lut.hip); valu_tile_kernel<JSD> skips tiles with equal non-zero classes.
+int po_launch_valu_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const unsigned long long* cls, uint64_t* tiles);
+size_t po_jsd_lut_workspace(uint64_t n, uint32_t dim);
+int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                           uint64_t npad, void* ws, const unsigned long long** cls_out);
+int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint64_t* tiles);
 int po_launch_gram_f64(po_ctx* ctx, int metric, const po_tile_args& a, uint64_t* tiles);
 int po_logtab_init(po_ctx* ctx);
 

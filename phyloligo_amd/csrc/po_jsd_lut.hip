@@ -1,0 +1,267 @@
+// Stage 2, JSD fast path for record pairs with EQUAL word totals: integer-sum table lookup.
+//
+// Same mathematics as valu_tile_kernel<JSD> (phylodist.JSD / KL,
+// /root/reference/phylopackage/core/phylodist.py:18-24, :43-48).  When two records have the same number
+// of counted words n (fixed-length contigs, sliding windows, simulated reads), the mixture
+// h = (a+b)/2 has h_w = (ca_w + cb_w) / 2n, so
+//     S = sum_w (a_w+b_w) ln(a_w+b_w) = (1/n) sum_w T[ca_w + cb_w] - 2 ln n,   T[x] = x ln x,
+// and the per-word, per-pair work collapses from a float64 logarithm to ONE integer add, ONE LDS read
+// and ONE float64 add.  T[x] for x = 0..127 sits in LDS replicated 32x (entry x, copy c at byte
+// x*256 + c*8) so that the per-lane lookups of a wave never conflict; counts are staged pre-shifted by 8
+// bits, so a lookup address is a single v_add3_u32.
+//
+// Eligibility is decided per tile on the device: classify_kernel marks each block of 128 records with its
+// common total (0 = mixed / empty / a count above 63); a tile (I,J) takes this path iff both classes are
+// equal and non-zero, every other tile is left to valu_tile_kernel<JSD>, which skips the marked ones.
+#include "po_internal.h"
+
+namespace {
+
+constexpr int TM = 128, TN = 128;
+constexpr int KC = 8;
+constexpr int kThreads = 256;
+constexpr int kLutEntries = 128;                       // sums 0..127  -> counts up to 63
+constexpr int kLutBytes = kLutEntries * 256;           // 32 copies x 8 B per entry
+constexpr int kStageWords = KC * (TM + TN);            // uint32 per buffer
+constexpr double LN2 = 0.693147180559945309417232121458;
+
+// Ct[d][npad] = counts[n][d] << 8 (uint32, transposed, zero padded to D8 x npad)
+__global__ __launch_bounds__(256) void prep_counts_kernel(const uint32_t* __restrict__ counts, uint64_t n, uint32_t dim,
+                                                          uint64_t npad, uint32_t* __restrict__ ct,
+                                                          uint32_t* __restrict__ maxcount) {
+    __shared__ uint32_t tile[64][65];
+    __shared__ uint32_t blkmax;
+    const uint64_t n0 = (uint64_t)blockIdx.x * 64;
+    const uint32_t d0 = blockIdx.y * 64;
+    const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (threadIdx.x == 0) blkmax = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (uint32_t r = ty; r < 64; r += 4) {
+        const uint64_t row = n0 + r;
+        const uint32_t v = (row < n && d0 + tx < dim) ? counts[row * dim + d0 + tx] : 0u;
+        mx = max(mx, v);
+        tile[r][tx] = v << 8;
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&blkmax, mx);
+    __syncthreads();
+    if (threadIdx.x == 0 && blkmax) atomicMax(maxcount, blkmax);
+    for (uint32_t r = ty; r < 64; r += 4)
+        if (d0 + r < ((dim + 7u) & ~7u) && n0 + tx < npad) ct[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r];
+}
+
+// cls[b] = common word total of records [128b, 128b+128) (padding ignored), 0 if they differ, if one is
+// empty, or if any count in the matrix exceeds what the table covers.
+__global__ __launch_bounds__(128) void classify_kernel(const unsigned long long* __restrict__ totals, uint64_t n,
+                                                       const uint32_t* __restrict__ maxcount,
+                                                       unsigned long long* __restrict__ cls) {
+    const uint64_t r = (uint64_t)blockIdx.x * 128 + threadIdx.x;
+    const uint64_t first = (uint64_t)blockIdx.x * 128;
+    const unsigned long long ref = totals[first];                     // first < n by construction of the grid
+    const bool ok = (r >= n) || (totals[r] == ref);
+    const int all = __syncthreads_and(ok ? 1 : 0);
+    if (threadIdx.x == 0) cls[blockIdx.x] = (all && ref > 0 && 2u * *maxcount < (uint32_t)kLutEntries) ? ref : 0ull;
+}
+
+__global__ void lut_table_kernel(double* __restrict__ lut) {
+    const uint32_t x = threadIdx.x;
+    if (x < kLutEntries) lut[x] = x ? (double)x * log((double)x) : 0.0;
+}
+
+struct TileCoord { uint32_t ti, tj; };
+__device__ __forceinline__ TileCoord tri_decode(uint64_t b, uint32_t T) {
+    const double tt = 2.0 * T + 1.0;
+    uint32_t i = (uint32_t)((tt - sqrt(tt * tt - 8.0 * (double)b)) * 0.5);
+    auto before = [T](uint64_t r) { return r * T - r * (r - 1) / 2; };
+    while (i > 0 && before(i) > b) --i;
+    while (before((uint64_t)i + 1) <= b) ++i;
+    return {i, (uint32_t)(i + (b - before(i)))};
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef const __attribute__((address_space(1))) unsigned char glb_byte;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)((const lds_byte*)p); }
+__device__ __forceinline__ double lds_read_f64(uint32_t addr) {
+    return *((const __attribute__((address_space(3))) double*)(uintptr_t)addr);
+}
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((glb_byte*)gptr, (lds_byte*)lds_base, 16, 0, 0);
+}
+#else
+__device__ __forceinline__ uint32_t lds_addr(const void*) { return 0; }
+__device__ __forceinline__ double lds_read_f64(uint32_t) { return 0.0; }
+__device__ __forceinline__ void glds16(const void*, void*) {}
+#endif
+
+template <typename OUT>
+__global__ __launch_bounds__(kThreads, 2) void jsd_lut_tile_kernel(po_tile_args A, const uint32_t* __restrict__ ct,
+                                                                   const double* __restrict__ lut,
+                                                                   const unsigned long long* __restrict__ cls,
+                                                                   uint32_t tiles_n, uint32_t tile_row0) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* tab = reinterpret_cast<double*>(smem);                               // [128][32]
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem + kLutBytes);             // [2][A: KC x 128 | B: KC x 128]
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t tx = t & 15, ty = t >> 4;
+    const uint32_t lane = t & 63, wave = t >> 6;
+
+    uint32_t ti, tj;
+    if (A.symmetric) {
+        const TileCoord c = tri_decode(blockIdx.x, tiles_n);
+        ti = c.ti; tj = c.tj;
+    } else {
+        ti = tile_row0 + blockIdx.x / tiles_n;
+        tj = blockIdx.x % tiles_n;
+    }
+    const unsigned long long ntot = cls[ti];
+    if (ntot == 0 || cls[tj] != ntot) return;                                    // valu_tile_kernel<JSD> owns this tile
+    const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
+
+    for (uint32_t e = t; e < kLutEntries * 32; e += kThreads) tab[e] = lut[e >> 5];
+
+    double acc[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
+
+    // staging: one LDS-DMA instruction moves 64 lanes x 16 B = two 512-byte word rows; wave w takes
+    // words 2w, 2w+1 of the A block and of the B block
+    auto gstage = [&](uint32_t k0, uint32_t buf) {
+        const uint32_t k = wave * 2 + (lane >> 5);
+        const uint32_t* row = ct + (uint64_t)(k0 + k) * A.npad + (lane & 31) * 4;
+        uint32_t* dst = stage + buf * kStageWords + wave * 2 * TM;
+        glds16(row + i0, dst);
+        glds16(row + j0, dst + KC * TM);
+    };
+    gstage(0, 0);
+    __syncthreads();
+
+    const uint32_t tcopy = lds_addr(tab) + (lane & 31) * 8;
+    uint32_t cur = 0;
+    for (uint32_t k0 = 0; k0 < A.dim; k0 += KC) {
+        if (k0 + KC < A.dim) gstage(k0 + KC, cur ^ 1);
+        const uint32_t* sA = stage + cur * kStageWords + ty * 8;
+        const uint32_t* sB = stage + cur * kStageWords + KC * TM + tx * 4;
+#pragma unroll 2
+        for (int k = 0; k < KC; ++k) {
+            const uint4 a0 = *reinterpret_cast<const uint4*>(sA + k * TM);
+            const uint4 a1 = *reinterpret_cast<const uint4*>(sA + k * TM + 4);
+            const uint4 b0 = *reinterpret_cast<const uint4*>(sB + k * TN);
+            const uint4 b1 = *reinterpret_cast<const uint4*>(sB + k * TN + 64);
+            const uint32_t a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const uint32_t b[8] = {b0.x + tcopy, b0.y + tcopy, b0.z + tcopy, b0.w + tcopy,
+                                   b1.x + tcopy, b1.y + tcopy, b1.z + tcopy, b1.w + tcopy};
+            // the 8 lookups of register-block row ia+1 are in flight while row ia is accumulated
+            double tv[2][8];
+#pragma unroll
+            for (int ib = 0; ib < 8; ++ib) tv[0][ib] = lds_read_f64(a[0] + b[ib]);
+#pragma unroll
+            for (int ia = 0; ia < 8; ++ia) {
+                if (ia + 1 < 8) {
+#pragma unroll
+                    for (int ib = 0; ib < 8; ++ib) tv[(ia + 1) & 1][ib] = lds_read_f64(a[ia + 1] + b[ib]);
+                }
+#pragma unroll
+                for (int ib = 0; ib < 8; ++ib) acc[ia][ib] += tv[ia & 1][ib];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: JSD = 1/2 (E_i + E_j - S) + ln 2,  S = Tsum/n - 2 ln n ----------------------------
+    const double inv_n = 1.0 / (double)ntot;
+    const double two_ln_n = 2.0 * log((double)ntot);
+    const double* st0 = A.rowstat;
+    double ei[8];
+#pragma unroll
+    for (int ia = 0; ia < 8; ++ia) ei[ia] = st0[i0 + ty * 8 + ia];
+    const bool mirror = A.symmetric && (ti != tj);
+#pragma unroll
+    for (int ib = 0; ib < 8; ++ib) {
+        const uint64_t j = j0 + 64 * (ib >> 2) + 4 * tx + (ib & 3);
+        if (j >= A.n) continue;
+        const double ej = st0[j];
+#pragma unroll
+        for (int ia = 0; ia < 8; ++ia) {
+            const uint64_t i = i0 + ty * 8 + ia;
+            if (i < A.row_begin || i >= A.row_end) continue;
+            const double S = fma(acc[ia][ib], inv_n, -two_ln_n);
+            double v = fmax(0.5 * (ei[ia] + ej - S) + LN2, 0.0);
+            if (i == j) v = 0.0;
+            if (sizeof(OUT) == 4) {
+                static_cast<float*>(A.out)[(i - A.row_begin) * A.ld_out + j] = (float)v;
+                if (mirror) static_cast<float*>(A.out)[j * A.ld_out + i] = (float)v;
+            } else {
+                static_cast<double*>(A.out)[(i - A.row_begin) * A.ld_out + j] = v;
+                if (mirror) static_cast<double*>(A.out)[j * A.ld_out + i] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+size_t po_jsd_lut_workspace(uint64_t n, uint32_t dim) {
+    const uint64_t npad = po_round_up(n ? n : 1, 128);
+    return po_round_up(dim, 8) * npad * sizeof(uint32_t)      // Ct
+           + npad / 128 * sizeof(unsigned long long)            // cls
+           + kLutEntries * sizeof(double) + 256;                // T + maxcount
+}
+
+// Builds Ct, the table and the tile classes in ws (layout as sized above); returns the class array.
+int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                           uint64_t npad, void* ws, const unsigned long long** cls_out) {
+    uint8_t* base = static_cast<uint8_t*>(ws);
+    uint32_t* ct = reinterpret_cast<uint32_t*>(base);
+    base += po_round_up(dim, 8) * npad * sizeof(uint32_t);
+    unsigned long long* cls = reinterpret_cast<unsigned long long*>(base);
+    base += npad / 128 * sizeof(unsigned long long);
+    double* lut = reinterpret_cast<double*>(base);
+    uint32_t* maxcount = reinterpret_cast<uint32_t*>(base + kLutEntries * sizeof(double));
+    PO_HIP(hipMemsetAsync(maxcount, 0, sizeof(uint32_t), ctx->stream));
+    dim3 grid((uint32_t)(npad / 64), (dim + 63) / 64);
+    hipLaunchKernelGGL(prep_counts_kernel, grid, dim3(256), 0, ctx->stream, d_counts, n, dim, npad, ct, maxcount);
+    PO_CHECK_LAUNCH("prep_counts_kernel");
+    hipLaunchKernelGGL(lut_table_kernel, dim3(1), dim3(kLutEntries), 0, ctx->stream, lut);
+    PO_CHECK_LAUNCH("lut_table_kernel");
+    hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, ctx->stream,
+                       reinterpret_cast<const unsigned long long*>(d_totals), n, maxcount, cls);
+    PO_CHECK_LAUNCH("classify_kernel");
+    *cls_out = cls;
+    return PO_OK;
+}
+
+int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint64_t* tiles) {
+    const uint8_t* base = static_cast<const uint8_t*>(ws);
+    const uint32_t* ct = reinterpret_cast<const uint32_t*>(base);
+    base += po_round_up(a.dim, 8) * a.npad * sizeof(uint32_t);
+    const unsigned long long* cls = reinterpret_cast<const unsigned long long*>(base);
+    base += a.npad / 128 * sizeof(unsigned long long);
+    const double* lut = reinterpret_cast<const double*>(base);
+
+    const uint32_t T = (uint32_t)((a.n + TN - 1) / TN);
+    uint64_t nblocks;
+    uint32_t tile_row0 = 0;
+    if (a.symmetric) {
+        nblocks = (uint64_t)T * (T + 1) / 2;
+    } else {
+        tile_row0 = (uint32_t)(a.row_begin / TM);
+        const uint32_t tile_row1 = (uint32_t)((a.row_end + TM - 1) / TM);
+        nblocks = (uint64_t)(tile_row1 - tile_row0) * T;
+    }
+    if (tiles) *tiles = nblocks;
+    if (nblocks == 0) return PO_OK;
+    if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
+    const size_t shmem = kLutBytes + 2 * kStageWords * sizeof(uint32_t);
+    if (a.out_f32)
+        hipLaunchKernelGGL(jsd_lut_tile_kernel<float>, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, ct, lut, cls, T, tile_row0);
+    else
+        hipLaunchKernelGGL(jsd_lut_tile_kernel<double>, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, ct, lut, cls, T, tile_row0);
+    PO_CHECK_LAUNCH("jsd_lut_tile_kernel");
+    return PO_OK;
+}

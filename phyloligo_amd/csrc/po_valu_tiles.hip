@@ -220,6 +220,7 @@ __device__ __forceinline__ void jsd_word(const JsdConsts& C, const double* s, in
 
 template <int METRIC, typename OUT, int VAR>
 __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, const double2* __restrict__ logtab,
+                                                                const unsigned long long* __restrict__ cls,
                                                                 uint32_t tiles_n, uint32_t tile_row0) {
     extern __shared__ __align__(16) unsigned char smem[];
     // the log table comes first so that a lane's lookup address is just (interval << 8 | copy)
@@ -236,6 +237,10 @@ __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, 
     } else {
         ti = tile_row0 + blockIdx.x / tiles_n;
         tj = blockIdx.x % tiles_n;
+    }
+    if (METRIC == PO_JSD && cls != nullptr) {          // tiles of equal-total record blocks belong to po_jsd_lut.hip
+        const unsigned long long c = cls[ti];
+        if (c != 0 && cls[tj] == c) return;
     }
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
 
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, 
 }
 
 template <int METRIC, int VAR>
-int launch_metric(po_ctx* ctx, const po_tile_args& a, uint64_t* tiles) {
+int launch_metric(po_ctx* ctx, const po_tile_args& a, const unsigned long long* cls, uint64_t* tiles) {
     const uint32_t T = (uint32_t)((a.n + TN - 1) / TN);
     uint64_t nblocks;
     uint32_t tile_row0 = 0;
@@ -369,11 +374,11 @@ int launch_metric(po_ctx* ctx, const po_tile_args& a, uint64_t* tiles) {
     if (a.out_f32) {
         auto k = valu_tile_kernel<METRIC, float, VAR>;
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, tab, T, tile_row0);
+        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, tab, cls, T, tile_row0);
     } else {
         auto k = valu_tile_kernel<METRIC, double, VAR>;
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, tab, T, tile_row0);
+        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, tab, cls, T, tile_row0);
     }
     PO_CHECK_LAUNCH("valu_tile_kernel");
     return PO_OK;
@@ -408,15 +413,15 @@ int po_logtab_init(po_ctx* ctx) {
     return PO_OK;
 }
 
-int po_launch_valu_tiles(po_ctx* ctx, int metric, const po_tile_args& a, uint64_t* tiles) {
+int po_launch_valu_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const unsigned long long* cls, uint64_t* tiles) {
     if (metric == PO_JSD) {
         int rc = po_logtab_init(ctx);
         if (rc) return rc;
         static const int variant = getenv("PO_JSD_VARIANT") ? atoi(getenv("PO_JSD_VARIANT")) : 0;
-        if (variant == 1) return launch_metric<PO_JSD, 1>(ctx, a, tiles);
-        return launch_metric<PO_JSD, 0>(ctx, a, tiles);
+        if (variant == 1) return launch_metric<PO_JSD, 1>(ctx, a, cls, tiles);
+        return launch_metric<PO_JSD, 0>(ctx, a, cls, tiles);
     }
-    if (metric == PO_BC) return launch_metric<PO_BC, 0>(ctx, a, tiles);
+    if (metric == PO_BC) return launch_metric<PO_BC, 0>(ctx, a, nullptr, tiles);
     po_set_error("po_launch_valu_tiles: metric %d is not an elementwise-reduction metric", metric);
     return PO_EINVAL;
 }

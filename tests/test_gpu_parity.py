@@ -150,3 +150,34 @@ def test_c1_config_full(ctx, golden_dir):
         far = m[np.ix_([0, 1, 2], [500, 777, 999])]
         np.testing.assert_allclose(far, g["far_" + metric], rtol=RTOL, atol=ATOL)
         assert np.array_equal(m, m.T)
+
+
+def test_jsd_equal_total_table_path_and_mixed_tiles(ctx):
+    """Equal-total record blocks take the integer-sum table kernel, the others the general kernel;
+    a mixed assembly exercises both inside one matrix, plus tiles that straddle the two."""
+    from oracle import phyloligo_oracle as po
+    rng = np.random.default_rng(11)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    fixed = [alpha[rng.integers(0, 4, size=1500)].tobytes() for _ in range(300)]          # totals all 2997
+    ragged = _random_assembly(200, 12, lo=500, hi=2500)
+    contigs = fixed[:256] + ragged[:100] + fixed[256:] + ragged[100:] + [b""]             # blocks: eq, eq, mixed...
+    seq, offsets = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, offsets, "1111", "both")
+    oc, ot = po.compute_counts(contigs, "1111", "both")
+    assert np.array_equal(counts.astype(np.int64), oc)
+    want = po.pairwise_block(po.counts_to_frequencies(oc, ot), "JSD")
+    got = ctx.pairwise(counts, totals, "JSD")
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(ctx.pairwise(counts, totals, "JSD", symmetric=False), want, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(ctx.pairwise(counts, totals, "JSD", row_begin=100, row_end=401), want[100:401],
+                               rtol=RTOL, atol=ATOL)
+    # all-equal assembly (the table kernel only) against the frequency entry point (general kernel only)
+    seq2, off2 = pack(fixed)
+    c2, t2 = ctx.count_profiles(seq2, off2, "1111", "both")
+    lut = ctx.pairwise(c2, t2, "JSD")
+    gen = ctx.pairwise_freq(ctx.frequencies(c2, t2), "JSD")
+    np.testing.assert_allclose(lut, gen, rtol=1e-9, atol=1e-13)
+    gen2, st = ctx.pairwise(c2, t2, "JSD", table_path=False, want_stats=True)
+    assert st["kernel_id"] == 1 and np.array_equal(gen2, gen)
+    o2c, o2t = po.compute_counts(fixed, "1111", "both")
+    np.testing.assert_allclose(lut, po.pairwise_block(po.counts_to_frequencies(o2c, o2t), "JSD"), rtol=RTOL, atol=ATOL)

@@ -7,6 +7,7 @@ from phyloligo_amd import synthetic
 n = int(sys.argv[1]); metric = sys.argv[2]; iters = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 pattern = sys.argv[4] if len(sys.argv) > 4 else "1111"
 ragged = len(sys.argv) > 5 and sys.argv[5] == "ragged"
+notable = len(sys.argv) > 6 and sys.argv[6] == "notable"
 ctx = pa.Context(0)
 if ragged:
     rng = np.random.default_rng(7)
@@ -19,5 +20,5 @@ dseq = torch.from_numpy(seq).cuda(); doff = torch.from_numpy(off.astype(np.int64
 counts, totals = ctx.count_profiles(dseq, doff, pattern, 'both')
 out = torch.empty((n, n), dtype=torch.float64, device='cuda')
 for it in range(iters):
-    _, st = ctx.pairwise(counts, totals, metric, out=out, want_stats=True)
+    _, st = ctx.pairwise(counts, totals, metric, out=out, want_stats=True, table_path=not notable)
     print(metric, n, pattern, 'kernel_ms %.3f total_ms %.3f pairs/s %.4e' % (st['kernel_ms'], st['total_ms'], n*(n-1)/2/(st['total_ms']*1e-3)))
