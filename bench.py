@@ -4,8 +4,9 @@
 A step = one pass of stage 2 (counts resident in HBM -> every matrix entry of this rank's shard
 resident in HBM, float64) over one synthetic assembly.  N=1: BASELINE config 2, 50,000 contigs x
 2 kb, k=4, both strands, -d JSD.  N>1: one process per GPU (torch.distributed, RCCL), the count
-matrix is all-gathered once, then every rank computes its row block with no further exchange;
-the assembly grows as 50,000*sqrt(N) contigs so that the pairs per GPU stay fixed (weak scaling).
+matrix is all-gathered once, then the upper triangle of the block grid is dealt out tournament-style
+(phyloligo_amd/dist.py) so that every pair is evaluated once, with no further exchange inside the timed
+region; the assembly grows as 50,000*sqrt(N) contigs so that the pairs per GPU stay fixed (weak scaling).
 """
 import argparse
 import json
@@ -69,7 +70,7 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local_rank)
 
-    n = int(round(args.contigs * math.sqrt(world)))
+    n = args.contigs if world == 1 else int(round(args.contigs * math.sqrt(world) / (256 * world))) * 256 * world
     seed = synthetic.SEEDS["C2"]
     plan = RowBlockPlan(n, world)
     ctx = pa.Context(local_rank)
@@ -88,11 +89,12 @@ def main():
     counts, totals = plan.all_gather_profiles(my_counts, my_totals, dist)
     dim = counts.shape[1]
     rows = hi - lo
-    out = torch.empty((rows, n), dtype=torch.float64, device=dev)
+    slab, mirrors = plan.allocate(rank, dev, torch.float64)     # this rank's rows x all columns (+ mirror blocks)
     ctx.reserve(n, dim, args.metric)
 
-    def step():
-        ctx.pairwise(counts, totals, args.metric, row_begin=lo, row_end=hi, out=out, symmetric=(world == 1))
+    def step(want_stats=False, table_path=True):
+        return plan.compute(ctx, counts, totals, args.metric, rank, slab, mirrors, want_stats=want_stats,
+                            table_path=table_path)
 
     for _ in range(args.warmup):
         step()
@@ -120,12 +122,11 @@ def main():
         # dominant kernel: HIP-event time of the tile kernel on the launch stream, averaged
         kms = []
         for _ in range(min(5, max(2, args.steps))):
-            _, st = ctx.pairwise(counts, totals, args.metric, row_begin=lo, row_end=hi, out=out,
-                                 symmetric=(world == 1), want_stats=True)
+            st = step(want_stats=True)
             kms.append(st["kernel_ms"])
         kernel_ms = float(np.mean(kms))
         main_kernel_id = st["kernel_id"]
-        rank_pairs = pairs if world == 1 else rows * n / 2.0
+        rank_pairs = float(plan.pair_evaluations(rank))
         # compulsory HBM bytes per unordered pair = two mirrored float64 outputs + the
         # amortised one-time read of both profiles (uint32 counts)
         bytes_per_pair = 2 * 8 + 2 * dim * 4 / (n - 1)
@@ -140,9 +141,7 @@ def main():
         if args.metric == "JSD":      # the same matrix through the general float64-log kernel only
             gms = []
             for _ in range(2):
-                _, st = ctx.pairwise(counts, totals, args.metric, row_begin=lo, row_end=hi, out=out,
-                                     symmetric=(world == 1), want_stats=True, table_path=False)
-                gms.append(st["total_ms"])
+                gms.append(step(want_stats=True, table_path=False)["total_ms"])
             general = {"ms": float(np.mean(gms)), "pairs_per_s": rank_pairs / (float(np.mean(gms)) * 1e-3)}
         kernel_names = {1: "valu_tile_kernel<JSD>", 2: "valu_tile_kernel<BC>", 3: "gram_tile_kernel (f64 MFMA)",
                         5: "kt_tile_kernel", 6: "jsd_lut_tile_kernel (equal-total record blocks) + valu_tile_kernel<JSD> (rest)"}

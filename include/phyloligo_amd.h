@@ -149,6 +149,25 @@ int po_pairwise_freq_dev(po_ctx* ctx, const double* d_freq, uint64_t n, uint32_t
                          uint64_t row_begin, uint64_t row_end, int out_dtype, void* d_out, uint64_t ld_out,
                          uint32_t flags, po_stats* stats);
 
+/* Several rectangular blocks of one matrix in one call (the per-rank work list of a multi-GPU run):
+ * the working layout is prepared once, then every block is launched.
+ *   out[(i-row_begin)*ld_out + (j-col_begin)]                      row_begin <= i < row_end, col_begin <= j < col_end
+ *   mirror[(j-col_begin)*ld_mirror + (i-row_begin)]  (if not NULL)  the transposed block, same values
+ * triangular != 0 requires rows == columns: only pairs i <= j are evaluated and the lower half is
+ * filled by symmetry inside `out` (mirror / ld_mirror are ignored).                                    */
+typedef struct po_block {
+    uint64_t row_begin, row_end, col_begin, col_end;
+    void* out;
+    uint64_t ld_out;
+    void* mirror;
+    uint64_t ld_mirror;
+    uint32_t triangular;
+    uint32_t reserved;
+} po_block;
+int po_pairwise_blocks_dev(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                           int metric, int out_dtype, const po_block* blocks, uint32_t n_blocks, uint32_t flags,
+                           po_stats* stats);
+
 /* bytes of device workspace po_pairwise_dev will hold for this problem (allocated lazily on
  * first use and kept by the context; call once before timing to keep hipMalloc out of it)    */
 int po_pairwise_reserve(po_ctx* ctx, uint64_t n, uint32_t dim, int metric);

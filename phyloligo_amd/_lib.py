@@ -26,6 +26,13 @@ class PoStats(ctypes.Structure):
                 ("reserved", ctypes.c_uint32)]
 
 
+class PoBlock(ctypes.Structure):
+    _fields_ = [("row_begin", ctypes.c_uint64), ("row_end", ctypes.c_uint64), ("col_begin", ctypes.c_uint64),
+                ("col_end", ctypes.c_uint64), ("out", ctypes.c_void_p), ("ld_out", ctypes.c_uint64),
+                ("mirror", ctypes.c_void_p), ("ld_mirror", ctypes.c_uint64), ("triangular", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
+
+
 class PhyloligoError(RuntimeError):
     def __init__(self, status, message):
         super().__init__("phyloligo_amd: %s (status %d)" % (message, status))
@@ -56,6 +63,7 @@ SIGNATURES = {
     "po_pairwise_dev": (_int, [_vp, _vp, _vp, _u64, _u32, _int, _u64, _u64, _int, _vp, _u64, _u32, _c.POINTER(PoStats)]),
     "po_pairwise_freq": (_int, [_vp, _vp, _u64, _u32, _int, _u64, _u64, _int, _vp, _u64, _u32, _c.POINTER(PoStats)]),
     "po_pairwise_freq_dev": (_int, [_vp, _vp, _u64, _u32, _int, _u64, _u64, _int, _vp, _u64, _u32, _c.POINTER(PoStats)]),
+    "po_pairwise_blocks_dev": (_int, [_vp, _vp, _vp, _u64, _u32, _int, _int, _c.POINTER(PoBlock), _u32, _u32, _c.POINTER(PoStats)]),
     "po_pairwise_reserve": (_int, [_vp, _u64, _u32, _int]),
     "po_fasta_scan": (_int, [_vp, _u64, _c.POINTER(_u64), _c.POINTER(_u64)]),
     "po_fasta_extract": (_int, [_vp, _u64, _vp, _vp, _vp, _vp]),

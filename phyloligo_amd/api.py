@@ -6,7 +6,8 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import METRICS, STRANDS, PO_F32, PO_F64, PO_FLAG_NO_SYMMETRY, PO_FLAG_NO_TABLE_PATH, PoStats, check
+from ._lib import (METRICS, STRANDS, PO_F32, PO_F64, PO_FLAG_NO_SYMMETRY, PO_FLAG_NO_TABLE_PATH, PoBlock, PoStats,
+                   check)
 
 
 def normalise_pattern(pattern):
@@ -133,6 +134,38 @@ class Context:
                       out=None, want_stats=False):
         """The same from a float64 frequency matrix (the reference's `frequencies` argument)."""
         return self._pairwise(None, None, freq, metric, row_begin, row_end, dtype, symmetric, out, want_stats)
+
+    def pairwise_blocks(self, counts, totals, metric, blocks, dtype="float64", want_stats=False, table_path=True):
+        """Several rectangular blocks of one matrix in one call (device tensors only).  `blocks` is a
+        list of dicts: rows=(lo,hi), cols=(lo,hi), out=<2-D tensor [rows, cols]>, optional
+        mirror=<2-D tensor [cols, rows]>, optional triangular=True (rows == cols)."""
+        import torch
+        f32 = str(dtype) in ("float32", "torch.float32", "f32")
+        want = torch.float32 if f32 else torch.float64
+        arr = (PoBlock * max(1, len(blocks)))()
+        for k, b in zip(arr, blocks):
+            (k.row_begin, k.row_end), (k.col_begin, k.col_end) = b["rows"], b["cols"]
+            out = b["out"]
+            assert out.dtype == want and out.is_cuda and out.dim() == 2 and out.stride(1) == 1
+            assert out.shape[0] >= k.row_end - k.row_begin and out.shape[1] >= k.col_end - k.col_begin
+            k.out, k.ld_out = out.data_ptr(), out.stride(0)
+            m = b.get("mirror")
+            if m is not None:
+                assert m.dtype == want and m.is_cuda and m.dim() == 2 and m.stride(1) == 1
+                assert m.shape[0] >= k.col_end - k.col_begin and m.shape[1] >= k.row_end - k.row_begin
+                k.mirror, k.ld_mirror = m.data_ptr(), m.stride(0)
+            k.triangular = 1 if b.get("triangular") else 0
+        n, dim = counts.shape
+        stats = PoStats()
+        self._use_torch_stream()
+        check(self._lib.po_pairwise_blocks_dev(self._h, counts.data_ptr(), totals.data_ptr(), n, dim, METRICS[metric],
+                                               PO_F32 if f32 else PO_F64, arr, len(blocks),
+                                               0 if table_path else PO_FLAG_NO_TABLE_PATH,
+                                               ctypes.byref(stats) if want_stats else None))
+        if want_stats:
+            return {"prep_ms": stats.prep_ms, "kernel_ms": stats.kernel_ms, "total_ms": stats.total_ms,
+                    "pairs": stats.pairs, "tiles": stats.tiles, "kernel_id": stats.kernel_id}
+        return None
 
     def _pairwise(self, counts, totals, freq, metric, row_begin, row_end, dtype, symmetric, out, want_stats,
                   extra_flags=0):

@@ -302,22 +302,38 @@ extern "C" int po_pairwise_reserve(po_ctx* ctx, uint64_t n, uint32_t dim, int me
     return reserve_pairwise(ctx, n, dim, metric);
 }
 
-// Exactly one of (d_counts,d_totals) / d_freq is given.
+// Exactly one of (d_counts,d_totals) / d_freq is given.  Prepares the working layout once, then
+// launches every block.
 static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts, const uint64_t* d_totals,
-                         const double* d_freq, uint64_t n, uint32_t dim, int metric, uint64_t row_begin,
-                         uint64_t row_end, int out_dtype, void* d_out, uint64_t ld_out, uint32_t flags,
-                         po_stats* stats) {
+                         const double* d_freq, uint64_t n, uint32_t dim, int metric, int out_dtype,
+                         const po_block* blocks, uint32_t n_blocks, uint32_t flags, po_stats* stats) {
     PO_REQUIRE(ctx != nullptr, "%s: ctx is NULL", who);
     int rc = check_metric(metric);
     if (rc) return rc;
     PO_REQUIRE(out_dtype == PO_F64 || out_dtype == PO_F32, "%s: out_dtype must be PO_F64 or PO_F32", who);
-    PO_REQUIRE(row_begin <= row_end && row_end <= n, "%s: row range [%llu,%llu) outside 0..%llu", who,
-               (unsigned long long)row_begin, (unsigned long long)row_end, (unsigned long long)n);
     PO_REQUIRE(dim >= 1, "%s: dim must be positive", who);
+    PO_REQUIRE(blocks != nullptr || n_blocks == 0, "%s: NULL block list", who);
     if (stats) memset(stats, 0, sizeof(*stats));
-    if (n == 0 || row_begin == row_end) return PO_OK;
-    PO_REQUIRE((d_freq != nullptr || (d_counts != nullptr && d_totals != nullptr)) && d_out != nullptr, "%s: NULL buffer", who);
-    PO_REQUIRE(ld_out >= n, "%s: ld_out (%llu) < n (%llu)", who, (unsigned long long)ld_out, (unsigned long long)n);
+    uint64_t entries = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const po_block& k = blocks[b];
+        PO_REQUIRE(k.row_begin <= k.row_end && k.row_end <= n && k.col_begin <= k.col_end && k.col_end <= n,
+                   "%s: block %u [%llu,%llu) x [%llu,%llu) outside 0..%llu", who, b, (unsigned long long)k.row_begin,
+                   (unsigned long long)k.row_end, (unsigned long long)k.col_begin, (unsigned long long)k.col_end,
+                   (unsigned long long)n);
+        if (k.row_begin == k.row_end || k.col_begin == k.col_end) continue;
+        PO_REQUIRE(k.out != nullptr, "%s: block %u has no output buffer", who, b);
+        PO_REQUIRE(k.ld_out >= k.col_end - k.col_begin, "%s: block %u: ld_out (%llu) < columns (%llu)", who, b,
+                   (unsigned long long)k.ld_out, (unsigned long long)(k.col_end - k.col_begin));
+        if (k.triangular)
+            PO_REQUIRE(k.row_begin == k.col_begin && k.row_end == k.col_end, "%s: block %u is triangular but rows != columns", who, b);
+        else if (k.mirror)
+            PO_REQUIRE(k.ld_mirror >= k.row_end - k.row_begin, "%s: block %u: ld_mirror (%llu) < rows (%llu)", who, b,
+                       (unsigned long long)k.ld_mirror, (unsigned long long)(k.row_end - k.row_begin));
+        entries += (k.row_end - k.row_begin) * (k.col_end - k.col_begin) * ((k.mirror && !k.triangular) ? 2 : 1);
+    }
+    if (n == 0 || entries == 0) return PO_OK;
+    PO_REQUIRE(d_freq != nullptr || (d_counts != nullptr && d_totals != nullptr), "%s: NULL buffer", who);
     PO_HIP(hipSetDevice(ctx->device));
 
     rc = reserve_pairwise(ctx, n, dim, metric);
@@ -326,22 +342,10 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     double* ft = static_cast<double*>(ctx->ws_freq.p);
     double* rowstat = static_cast<double*>(ctx->ws_rowstat.p);
 
-    po_tile_args a;
-    a.ft = ft;
-    a.rowstat = rowstat;
-    a.n = n;
-    a.npad = npad;
-    a.dim = dim;
-    a.row_begin = row_begin;
-    a.row_end = row_end;
-    a.out = d_out;
-    a.ld_out = ld_out;
-    a.out_f32 = (out_dtype == PO_F32);
-    a.symmetric = (row_begin == 0 && row_end == n && !(flags & PO_FLAG_NO_SYMMETRY)) ? 1 : 0;
-
     if (stats) PO_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    // ---- prep: working layout + per-row terms ----
+    // ---- prep: working layout + per-row terms (once) ----
     uint32_t* lessrank = nullptr;
+    const unsigned long long* cls = nullptr;
     if (metric == PO_EUCL || metric == PO_JSD || metric == PO_BC) {
         rc = d_freq ? po_launch_prep_freq(ctx, d_freq, n, dim, npad, ft)
                     : po_launch_prep(ctx, d_counts, d_totals, n, dim, npad, ft);
@@ -356,31 +360,54 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, nullptr, lessrank, rowstat);
     }
     if (rc) return rc;
+    if (metric == PO_EUCL || metric == PO_SC) {
+        rc = po_launch_gram_norms(ctx, ft, dim, npad, rowstat);
+        if (rc) return rc;
+    }
+    if (metric == PO_JSD && d_counts && !(flags & PO_FLAG_NO_TABLE_PATH)) {
+        // record blocks with one common word total go through the integer-sum table kernel, the rest
+        // through the general float64 kernel; each launch skips the other's tiles (decided on device)
+        rc = po_launch_jsd_lut_prep(ctx, d_counts, d_totals, n, dim, npad, ctx->ws_aux.p, &cls);
+        if (rc) return rc;
+    }
     if (stats) PO_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-    // ---- tiles ----
+
+    // ---- tiles, block by block ----
     uint64_t tiles = 0;
     uint32_t kid = 0;
-    switch (metric) {
-        case PO_JSD: {
-            // record blocks with one common word total go through the integer-sum table kernel, the rest
-            // through the general float64 kernel; each launch skips the other's tiles (decided on device)
-            const unsigned long long* cls = nullptr;
-            if (d_counts && !(flags & PO_FLAG_NO_TABLE_PATH)) {
-                rc = po_launch_jsd_lut_prep(ctx, d_counts, d_totals, n, dim, npad, ctx->ws_aux.p, &cls);
-                if (rc) return rc;
-                rc = po_launch_jsd_lut_tiles(ctx, a, ctx->ws_aux.p, &tiles);
-                if (rc) return rc;
-            }
-            rc = po_launch_valu_tiles(ctx, PO_JSD, a, cls, &tiles);
-            kid = cls ? PO_KERNEL_LUT_JSD : PO_KERNEL_VALU_JSD;
-            break;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const po_block& k = blocks[b];
+        if (k.row_begin == k.row_end || k.col_begin == k.col_end) continue;
+        po_tile_args a;
+        a.ft = ft;
+        a.rowstat = rowstat;
+        a.n = n;
+        a.npad = npad;
+        a.dim = dim;
+        a.row_begin = k.row_begin; a.row_end = k.row_end;
+        a.col_begin = k.col_begin; a.col_end = k.col_end;
+        a.out = k.out;
+        a.ld_out = k.ld_out;
+        a.triangular = k.triangular ? 1 : 0;
+        a.mirror = k.triangular ? k.out : k.mirror;
+        a.ld_mirror = k.triangular ? k.ld_out : k.ld_mirror;
+        a.out_f32 = (out_dtype == PO_F32);
+        switch (metric) {
+            case PO_JSD:
+                if (cls) {
+                    rc = po_launch_jsd_lut_tiles(ctx, a, n, ctx->ws_aux.p, &tiles);
+                    if (rc) return rc;
+                }
+                rc = po_launch_valu_tiles(ctx, PO_JSD, a, cls, cls ? nullptr : &tiles);
+                kid = cls ? PO_KERNEL_LUT_JSD : PO_KERNEL_VALU_JSD;
+                break;
+            case PO_BC: rc = po_launch_valu_tiles(ctx, PO_BC, a, nullptr, &tiles); kid = PO_KERNEL_VALU_BC; break;
+            case PO_EUCL: rc = po_launch_gram_f64(ctx, PO_EUCL, a, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
+            case PO_SC: rc = po_launch_gram_f64(ctx, PO_SC, a, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
+            case PO_KT: rc = po_launch_kt(ctx, lessrank, n, dim, a, &tiles); kid = PO_KERNEL_VALU_KT; break;
         }
-        case PO_BC: rc = po_launch_valu_tiles(ctx, PO_BC, a, nullptr, &tiles); kid = PO_KERNEL_VALU_BC; break;
-        case PO_EUCL: rc = po_launch_gram_f64(ctx, PO_EUCL, a, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
-        case PO_SC: rc = po_launch_gram_f64(ctx, PO_SC, a, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
-        case PO_KT: rc = po_launch_kt(ctx, lessrank, n, dim, a, &tiles); kid = PO_KERNEL_VALU_KT; break;
+        if (rc) return rc;
     }
-    if (rc) return rc;
     if (stats) {
         PO_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
         PO_HIP(hipEventSynchronize(ctx->ev[2]));
@@ -391,27 +418,60 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         stats->kernel_ms = ms;
         PO_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[2]));
         stats->total_ms = ms;
-        stats->pairs = (row_end - row_begin) * n / 2;
+        stats->pairs = entries / 2;
         stats->tiles = tiles;
         stats->kernel_id = kid;
     }
     return PO_OK;
 }
 
+// rows [row_begin,row_end) x all columns as one block; the full matrix is one triangular block
+static po_block rows_block(uint64_t n, uint64_t row_begin, uint64_t row_end, void* out, uint64_t ld_out, uint32_t flags) {
+    po_block k;
+    memset(&k, 0, sizeof(k));
+    k.row_begin = row_begin; k.row_end = row_end;
+    k.col_begin = 0; k.col_end = n;
+    k.out = out; k.ld_out = ld_out;
+    k.triangular = (row_begin == 0 && row_end == n && !(flags & PO_FLAG_NO_SYMMETRY)) ? 1u : 0u;
+    return k;
+}
+
+static int check_rows(const char* who, uint64_t n, uint64_t row_begin, uint64_t row_end, const void* out, uint64_t ld_out) {
+    PO_REQUIRE(row_begin <= row_end && row_end <= n, "%s: row range [%llu,%llu) outside 0..%llu", who,
+               (unsigned long long)row_begin, (unsigned long long)row_end, (unsigned long long)n);
+    if (n == 0 || row_begin == row_end) return PO_OK;
+    PO_REQUIRE(out != nullptr, "%s: NULL buffer", who);
+    PO_REQUIRE(ld_out >= n, "%s: ld_out (%llu) < n (%llu)", who, (unsigned long long)ld_out, (unsigned long long)n);
+    return PO_OK;
+}
+
 extern "C" int po_pairwise_dev(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
                                uint32_t dim, int metric, uint64_t row_begin, uint64_t row_end, int out_dtype,
                                void* d_out, uint64_t ld_out, uint32_t flags, po_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    int rc = check_rows("po_pairwise_dev", n, row_begin, row_end, d_out, ld_out);
+    if (rc) return rc;
     if (n && row_begin != row_end && (!d_counts || !d_totals)) { po_set_error("po_pairwise_dev: NULL buffer"); return PO_EINVAL; }
-    return pairwise_core(ctx, "po_pairwise_dev", d_counts, d_totals, nullptr, n, dim, metric, row_begin, row_end,
-                         out_dtype, d_out, ld_out, flags, stats);
+    const po_block k = rows_block(n, row_begin, row_end, d_out, ld_out, flags);
+    return pairwise_core(ctx, "po_pairwise_dev", d_counts, d_totals, nullptr, n, dim, metric, out_dtype, &k, 1, flags, stats);
 }
 
 extern "C" int po_pairwise_freq_dev(po_ctx* ctx, const double* d_freq, uint64_t n, uint32_t dim, int metric,
                                     uint64_t row_begin, uint64_t row_end, int out_dtype, void* d_out,
                                     uint64_t ld_out, uint32_t flags, po_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    int rc = check_rows("po_pairwise_freq_dev", n, row_begin, row_end, d_out, ld_out);
+    if (rc) return rc;
     if (n && row_begin != row_end && !d_freq) { po_set_error("po_pairwise_freq_dev: NULL buffer"); return PO_EINVAL; }
-    return pairwise_core(ctx, "po_pairwise_freq_dev", nullptr, nullptr, d_freq, n, dim, metric, row_begin, row_end,
-                         out_dtype, d_out, ld_out, flags, stats);
+    const po_block k = rows_block(n, row_begin, row_end, d_out, ld_out, flags);
+    return pairwise_core(ctx, "po_pairwise_freq_dev", nullptr, nullptr, d_freq, n, dim, metric, out_dtype, &k, 1, flags, stats);
+}
+
+extern "C" int po_pairwise_blocks_dev(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
+                                      uint32_t dim, int metric, int out_dtype, const po_block* blocks,
+                                      uint32_t n_blocks, uint32_t flags, po_stats* stats) {
+    return pairwise_core(ctx, "po_pairwise_blocks_dev", d_counts, d_totals, nullptr, n, dim, metric, out_dtype, blocks,
+                         n_blocks, flags, stats);
 }
 
 // host-pointer forms: stage in ws_io, run the device form, copy the rows back
@@ -445,13 +505,15 @@ static int pairwise_host(po_ctx* ctx, const char* who, const uint32_t* counts, c
     void* d_out = base + b_in + b_tot;
     if (freq) {
         PO_HIP(hipMemcpyAsync(d_in, freq, n * (uint64_t)dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        rc = pairwise_core(ctx, who, nullptr, nullptr, static_cast<const double*>(d_in), n, dim, metric, row_begin,
-                           row_end, out_dtype, d_out, n, flags, stats);
+        const po_block k = rows_block(n, row_begin, row_end, d_out, n, flags);
+        rc = pairwise_core(ctx, who, nullptr, nullptr, static_cast<const double*>(d_in), n, dim, metric, out_dtype, &k, 1,
+                           flags, stats);
     } else {
         PO_HIP(hipMemcpyAsync(d_in, counts, n * (uint64_t)dim * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         PO_HIP(hipMemcpyAsync(d_tot, totals, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-        rc = pairwise_core(ctx, who, static_cast<const uint32_t*>(d_in), d_tot, nullptr, n, dim, metric, row_begin,
-                           row_end, out_dtype, d_out, n, flags, stats);
+        const po_block k = rows_block(n, row_begin, row_end, d_out, n, flags);
+        rc = pairwise_core(ctx, who, static_cast<const uint32_t*>(d_in), d_tot, nullptr, n, dim, metric, out_dtype, &k, 1,
+                           flags, stats);
     }
     if (rc) return rc;
     PO_HIP(hipMemcpy2DAsync(out, ld_out * esz, d_out, n * esz, n * esz, rows, hipMemcpyDeviceToHost, ctx->stream));

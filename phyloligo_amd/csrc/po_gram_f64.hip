@@ -12,7 +12,7 @@
 // 8 words at a time through double-buffered LDS.  The squared norms come from the SAME
 // instruction sequence run on the diagonal 16 x 16 blocks, so that two identical records give
 // |a|^2 + |a|^2 - 2 a.a = 0 exactly, as the reference's (a-b)^2 form does.
-#include "po_internal.h"
+#include "po_tiles.h"
 
 namespace {
 
@@ -24,24 +24,8 @@ constexpr int kThreads = 256;
 constexpr int kRowStride = TM + TN + 16;          // +16 doubles: k-rows of one MFMA operand land in
 constexpr int kStageDoubles = KC * kRowStride;    // different bank halves (ds_read_b64, 32-lane groups)
 
-struct TileCoord { uint32_t ti, tj; };
 
-__device__ __forceinline__ TileCoord tri_decode(uint64_t b, uint32_t T) {
-    const double tt = 2.0 * T + 1.0;
-    uint32_t i = (uint32_t)((tt - sqrt(tt * tt - 8.0 * (double)b)) * 0.5);
-    auto before = [T](uint64_t r) { return r * T - r * (r - 1) / 2; };
-    while (i > 0 && before(i) > b) --i;
-    while (before((uint64_t)i + 1) <= b) ++i;
-    return {i, (uint32_t)(i + (b - before(i)))};
-}
 
-template <typename T> __device__ __forceinline__ void store_out(void* out, uint64_t idx, double v);
-template <> __device__ __forceinline__ void store_out<double>(void* out, uint64_t idx, double v) {
-    static_cast<double*>(out)[idx] = v;
-}
-template <> __device__ __forceinline__ void store_out<float>(void* out, uint64_t idx, double v) {
-    static_cast<float*>(out)[idx] = (float)v;
-}
 
 // |x_r|^2 for 16 records per wave, by the same k-ascending MFMA chain the tile kernel uses.
 __global__ __launch_bounds__(64) void gram_diag_kernel(const double* __restrict__ xt, uint32_t dim, uint64_t npad,
@@ -64,8 +48,7 @@ __global__ __launch_bounds__(64) void gram_diag_kernel(const double* __restrict_
 }
 
 template <int METRIC, typename OUT>
-__global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, const double* __restrict__ norms,
-                                                                uint32_t tiles_n, uint32_t tile_row0) {
+__global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, const double* __restrict__ norms) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* stage = reinterpret_cast<double*>(smem);                    // [2][KC][kRowStride]
 
@@ -75,13 +58,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
     const uint32_t lc = lane & 15, lg = lane >> 4;
 
     uint32_t ti, tj;
-    if (A.symmetric) {
-        const TileCoord c = tri_decode(blockIdx.x, tiles_n);
-        ti = c.ti; tj = c.tj;
-    } else {
-        ti = tile_row0 + blockIdx.x / tiles_n;
-        tj = blockIdx.x % tiles_n;
-    }
+    po_tile_coords(A, TM, blockIdx.x, ti, tj);
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
 
     double4_t acc[4][4];
@@ -145,7 +122,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
     }
 
     // ---- epilogue: lane holds rows lg + 4*reg, column lc of each 16 x 16 block -------------------
-    const bool mirror = A.symmetric && (ti != tj);
+    const bool mirror = po_tile_mirrors(A, ti, tj);
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const uint64_t j = j0 + wc * 64 + n * 16 + lc;
@@ -156,7 +133,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const uint64_t i = i0 + wr * 64 + m * 16 + lg + 4 * reg;
-                if (i < A.row_begin || i >= A.row_end) continue;
+                if (!po_in_block(A, i, j)) continue;
                 const double g = acc[m][n][reg];
                 const double ni = norms[i];
                 double v;
@@ -166,8 +143,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
                 } else {  // PO_SC: 1 - Pearson correlation of the centred ranks; constant row -> NaN
                     v = 1.0 - g / sqrt(ni * nj);
                 }
-                store_out<OUT>(A.out, (i - A.row_begin) * A.ld_out + j, v);
-                if (mirror) store_out<OUT>(A.out, j * A.ld_out + i, v);
+                po_store_pair<OUT>(A, i, j, v, mirror);
             }
         }
     }
@@ -175,39 +151,31 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
 
 template <int METRIC>
 int launch_gram(po_ctx* ctx, const po_tile_args& a, const double* norms, uint64_t* tiles) {
-    const uint32_t T = (uint32_t)((a.n + TN - 1) / TN);
-    uint64_t nblocks;
-    uint32_t tile_row0 = 0;
-    if (a.symmetric) {
-        nblocks = (uint64_t)T * (T + 1) / 2;
-    } else {
-        tile_row0 = (uint32_t)(a.row_begin / TM);
-        const uint32_t tile_row1 = (uint32_t)((a.row_end + TM - 1) / TM);
-        nblocks = (uint64_t)(tile_row1 - tile_row0) * T;
-    }
-    if (tiles) *tiles = nblocks;
+    const uint64_t nblocks = po_tile_count(a, TM);
+    if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
     const size_t shmem = 2 * kStageDoubles * sizeof(double);
-    if (a.out_f32) {
-        hipLaunchKernelGGL((gram_tile_kernel<METRIC, float>), dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream,
-                           a, norms, T, tile_row0);
-    } else {
-        hipLaunchKernelGGL((gram_tile_kernel<METRIC, double>), dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream,
-                           a, norms, T, tile_row0);
-    }
+    if (a.out_f32)
+        hipLaunchKernelGGL((gram_tile_kernel<METRIC, float>), dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, norms);
+    else
+        hipLaunchKernelGGL((gram_tile_kernel<METRIC, double>), dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, norms);
     PO_CHECK_LAUNCH("gram_tile_kernel");
     return PO_OK;
 }
 
 }  // namespace
 
-// a.ft is the operand matrix (frequencies for Eucl, centred ranks for SC); the squared norms go
-// to rowstat[2][npad].
-int po_launch_gram_f64(po_ctx* ctx, int metric, const po_tile_args& a, uint64_t* tiles) {
-    double* norms = const_cast<double*>(a.rowstat) + 2 * a.npad;
-    hipLaunchKernelGGL(gram_diag_kernel, dim3((uint32_t)(a.npad / 16)), dim3(64), 0, ctx->stream, a.ft, a.dim, a.npad, norms);
+// squared norms of every operand row into rowstat[2][npad] (once per problem, before the tile launches)
+int po_launch_gram_norms(po_ctx* ctx, const double* ft, uint32_t dim, uint64_t npad, double* rowstat) {
+    hipLaunchKernelGGL(gram_diag_kernel, dim3((uint32_t)(npad / 16)), dim3(64), 0, ctx->stream, ft, dim, npad, rowstat + 2 * npad);
     PO_CHECK_LAUNCH("gram_diag_kernel");
+    return PO_OK;
+}
+
+// a.ft is the operand matrix (frequencies for Eucl, centred ranks for SC)
+int po_launch_gram_f64(po_ctx* ctx, int metric, const po_tile_args& a, uint64_t* tiles) {
+    const double* norms = a.rowstat + 2 * a.npad;
     if (metric == PO_EUCL) return launch_gram<PO_EUCL>(ctx, a, norms, tiles);
     if (metric == PO_SC) return launch_gram<PO_SC>(ctx, a, norms, tiles);
     po_set_error("po_launch_gram_f64: metric %d is not a Gram-form metric", metric);

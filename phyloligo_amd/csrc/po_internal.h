@@ -93,16 +93,20 @@ int po_launch_freq_rowmajor(po_ctx* ctx, const uint32_t* d_counts, const uint64_
 // rowstat[0][n] = sum f ln f, rowstat[1][n] = sum f
 int po_launch_rowstat(po_ctx* ctx, const double* d_ft, uint64_t n, uint32_t dim, uint64_t npad, double* d_rowstat);
 
+// One rectangular block of the matrix handed to a tile kernel.
 struct po_tile_args {
-    const double* ft;       // [dim][npad]
+    const double* ft;       // operand matrix [dim8][npad] (frequencies or centred ranks)
     const double* rowstat;  // [4][npad]
     uint64_t n, npad;
     uint32_t dim;
-    uint64_t row_begin, row_end;   // output rows
-    void* out;
+    uint64_t row_begin, row_end;   // rows of the block (absolute record indices)
+    uint64_t col_begin, col_end;   // columns of the block
+    void* out;              // out[(i-row_begin)*ld_out + (j-col_begin)]
     uint64_t ld_out;
+    void* mirror;           // optional transpose target: mirror[(j-col_begin)*ld_mirror + (i-row_begin)]
+    uint64_t ld_mirror;
     int out_f32;
-    int symmetric;          // 1: only tiles on/above the diagonal are computed, mirrored on store
+    int triangular;         // rows == columns: only tiles on/above the diagonal are computed (mirror = out)
 };
 // cls (may be NULL): per 128-record block, the common word total if the equal-total table path owns
 // the tiles of that class (po_jsd_lut.hip); valu_tile_kernel<JSD> skips tiles with equal non-zero classes.
@@ -110,7 +114,8 @@ int po_launch_valu_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const u
 size_t po_jsd_lut_workspace(uint64_t n, uint32_t dim);
 int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
                            uint64_t npad, void* ws, const unsigned long long** cls_out);
-int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint64_t* tiles);
+int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, const void* ws, uint64_t* tiles);
+int po_launch_gram_norms(po_ctx* ctx, const double* ft, uint32_t dim, uint64_t npad, double* rowstat);
 int po_launch_gram_f64(po_ctx* ctx, int metric, const po_tile_args& a, uint64_t* tiles);
 int po_logtab_init(po_ctx* ctx);
 

@@ -13,7 +13,7 @@
 // Eligibility is decided per tile on the device: classify_kernel marks each block of 128 records with its
 // common total (0 = mixed / empty / a count above 63); a tile (I,J) takes this path iff both classes are
 // equal and non-zero, every other tile is left to valu_tile_kernel<JSD>, which skips the marked ones.
-#include "po_internal.h"
+#include "po_tiles.h"
 
 namespace {
 
@@ -69,15 +69,6 @@ __global__ void lut_table_kernel(double* __restrict__ lut) {
     if (x < kLutEntries) lut[x] = x ? (double)x * log((double)x) : 0.0;
 }
 
-struct TileCoord { uint32_t ti, tj; };
-__device__ __forceinline__ TileCoord tri_decode(uint64_t b, uint32_t T) {
-    const double tt = 2.0 * T + 1.0;
-    uint32_t i = (uint32_t)((tt - sqrt(tt * tt - 8.0 * (double)b)) * 0.5);
-    auto before = [T](uint64_t r) { return r * T - r * (r - 1) / 2; };
-    while (i > 0 && before(i) > b) --i;
-    while (before((uint64_t)i + 1) <= b) ++i;
-    return {i, (uint32_t)(i + (b - before(i)))};
-}
 
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -98,8 +89,7 @@ __device__ __forceinline__ void glds16(const void*, void*) {}
 template <typename OUT>
 __global__ __launch_bounds__(kThreads, 2) void jsd_lut_tile_kernel(po_tile_args A, const uint32_t* __restrict__ ct,
                                                                    const double* __restrict__ lut,
-                                                                   const unsigned long long* __restrict__ cls,
-                                                                   uint32_t tiles_n, uint32_t tile_row0) {
+                                                                   const unsigned long long* __restrict__ cls) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* tab = reinterpret_cast<double*>(smem);                               // [128][32]
     uint32_t* stage = reinterpret_cast<uint32_t*>(smem + kLutBytes);             // [2][A: KC x 128 | B: KC x 128]
@@ -109,13 +99,7 @@ __global__ __launch_bounds__(kThreads, 2) void jsd_lut_tile_kernel(po_tile_args 
     const uint32_t lane = t & 63, wave = t >> 6;
 
     uint32_t ti, tj;
-    if (A.symmetric) {
-        const TileCoord c = tri_decode(blockIdx.x, tiles_n);
-        ti = c.ti; tj = c.tj;
-    } else {
-        ti = tile_row0 + blockIdx.x / tiles_n;
-        tj = blockIdx.x % tiles_n;
-    }
+    po_tile_coords(A, TM, blockIdx.x, ti, tj);
     const unsigned long long ntot = cls[ti];
     if (ntot == 0 || cls[tj] != ntot) return;                                    // valu_tile_kernel<JSD> owns this tile
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
@@ -180,7 +164,7 @@ __global__ __launch_bounds__(kThreads, 2) void jsd_lut_tile_kernel(po_tile_args 
     double ei[8];
 #pragma unroll
     for (int ia = 0; ia < 8; ++ia) ei[ia] = st0[i0 + ty * 8 + ia];
-    const bool mirror = A.symmetric && (ti != tj);
+    const bool mirror = po_tile_mirrors(A, ti, tj);
 #pragma unroll
     for (int ib = 0; ib < 8; ++ib) {
         const uint64_t j = j0 + 64 * (ib >> 2) + 4 * tx + (ib & 3);
@@ -189,17 +173,11 @@ __global__ __launch_bounds__(kThreads, 2) void jsd_lut_tile_kernel(po_tile_args 
 #pragma unroll
         for (int ia = 0; ia < 8; ++ia) {
             const uint64_t i = i0 + ty * 8 + ia;
-            if (i < A.row_begin || i >= A.row_end) continue;
+            if (!po_in_block(A, i, j)) continue;
             const double S = fma(acc[ia][ib], inv_n, -two_ln_n);
             double v = fmax(0.5 * (ei[ia] + ej - S) + LN2, 0.0);
             if (i == j) v = 0.0;
-            if (sizeof(OUT) == 4) {
-                static_cast<float*>(A.out)[(i - A.row_begin) * A.ld_out + j] = (float)v;
-                if (mirror) static_cast<float*>(A.out)[j * A.ld_out + i] = (float)v;
-            } else {
-                static_cast<double*>(A.out)[(i - A.row_begin) * A.ld_out + j] = v;
-                if (mirror) static_cast<double*>(A.out)[j * A.ld_out + i] = v;
-            }
+            po_store_pair<OUT>(A, i, j, v, mirror);
         }
     }
 }
@@ -236,32 +214,23 @@ int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t
     return PO_OK;
 }
 
-int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint64_t* tiles) {
+int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, const void* ws, uint64_t* tiles) {
     const uint8_t* base = static_cast<const uint8_t*>(ws);
     const uint32_t* ct = reinterpret_cast<const uint32_t*>(base);
     base += po_round_up(a.dim, 8) * a.npad * sizeof(uint32_t);
     const unsigned long long* cls = reinterpret_cast<const unsigned long long*>(base);
     base += a.npad / 128 * sizeof(unsigned long long);
     const double* lut = reinterpret_cast<const double*>(base);
-
-    const uint32_t T = (uint32_t)((a.n + TN - 1) / TN);
-    uint64_t nblocks;
-    uint32_t tile_row0 = 0;
-    if (a.symmetric) {
-        nblocks = (uint64_t)T * (T + 1) / 2;
-    } else {
-        tile_row0 = (uint32_t)(a.row_begin / TM);
-        const uint32_t tile_row1 = (uint32_t)((a.row_end + TM - 1) / TM);
-        nblocks = (uint64_t)(tile_row1 - tile_row0) * T;
-    }
-    if (tiles) *tiles = nblocks;
+    (void)n;
+    const uint64_t nblocks = po_tile_count(a, TM);
+    if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
     const size_t shmem = kLutBytes + 2 * kStageWords * sizeof(uint32_t);
     if (a.out_f32)
-        hipLaunchKernelGGL(jsd_lut_tile_kernel<float>, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, ct, lut, cls, T, tile_row0);
+        hipLaunchKernelGGL(jsd_lut_tile_kernel<float>, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, ct, lut, cls);
     else
-        hipLaunchKernelGGL(jsd_lut_tile_kernel<double>, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, ct, lut, cls, T, tile_row0);
+        hipLaunchKernelGGL(jsd_lut_tile_kernel<double>, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, ct, lut, cls);
     PO_CHECK_LAUNCH("jsd_lut_tile_kernel");
     return PO_OK;
 }

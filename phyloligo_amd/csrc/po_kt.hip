@@ -10,7 +10,7 @@
 // so only  S = con - dis = sum_{p<q} sgn(x_p - x_q) sgn(y_p - y_q)  depends on the record pair.
 // Ranks and ties of frequencies equal those of the integer counts (same positive divisor per
 // record), so everything here is exact integer work until the final division.
-#include "po_internal.h"
+#include "po_tiles.h"
 
 namespace {
 
@@ -71,32 +71,16 @@ __global__ __launch_bounds__(kThreads) void zero_pad_kernel(double* __restrict__
         rt[(i / pad) * npad + n + (i % pad)] = 0.0;
 }
 
-struct TileCoord { uint32_t ti, tj; };
-__device__ __forceinline__ TileCoord tri_decode(uint64_t b, uint32_t T) {
-    const double tt = 2.0 * T + 1.0;
-    uint32_t i = (uint32_t)((tt - sqrt(tt * tt - 8.0 * (double)b)) * 0.5);
-    auto before = [T](uint64_t r) { return r * T - r * (r - 1) / 2; };
-    while (i > 0 && before(i) > b) --i;
-    while (before((uint64_t)i + 1) <= b) ++i;
-    return {i, (uint32_t)(i + (b - before(i)))};
-}
 
 __device__ __forceinline__ int sgn_i32(int v) { return min(max(v, -1), 1); }   // v_med3_i32
 
 template <typename OUT>
-__global__ __launch_bounds__(kThreads) void kt_tile_kernel(const uint32_t* __restrict__ counts, po_tile_args A,
-                                                           uint32_t tiles_n, uint32_t tile_row0) {
+__global__ __launch_bounds__(kThreads) void kt_tile_kernel(const uint32_t* __restrict__ counts, po_tile_args A) {
     __shared__ int xa_p[PT][kRow], xb_p[PT][kRow], xa_q[PT][kRow], xb_q[PT][kRow];
     const uint32_t t = threadIdx.x;
     const uint32_t pi = t >> 4, pj = t & 15;
     uint32_t ti, tj;
-    if (A.symmetric) {
-        const TileCoord c = tri_decode(blockIdx.x, tiles_n);
-        ti = c.ti; tj = c.tj;
-    } else {
-        ti = tile_row0 + blockIdx.x / tiles_n;
-        tj = blockIdx.x % tiles_n;
-    }
+    po_tile_coords(A, PT, blockIdx.x, ti, tj);
     const uint64_t i0 = (uint64_t)ti * PT, j0 = (uint64_t)tj * PT;
 
     auto load_chunk = [&](int (*dst)[kRow], uint64_t r0, uint32_t c0) {
@@ -131,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void kt_tile_kernel(const uint32_t* __res
     }
 
     const uint64_t i = i0 + pi, j = j0 + pj;
-    if (i >= A.n || j >= A.n || i < A.row_begin || i >= A.row_end) return;
+    if (i >= A.n || j >= A.n || !po_in_block(A, i, j)) return;
     const double T = 0.5 * (double)A.dim * ((double)A.dim - 1.0);
     const double* ties = A.rowstat + 3 * A.npad;
     const double dx = T - ties[j], dy = T - ties[i];     // con+dis+exx, con+dis+exy
@@ -142,13 +126,7 @@ __global__ __launch_bounds__(kThreads) void kt_tile_kernel(const uint32_t* __res
         const double tau = (double)S / sqrt(dx * dy);
         v = 1.0 - (1.0 - tau);
     }
-    if (A.out_f32) {
-        static_cast<float*>(A.out)[(i - A.row_begin) * A.ld_out + j] = (float)v;
-        if (A.symmetric && ti != tj) static_cast<float*>(A.out)[j * A.ld_out + i] = (float)v;
-    } else {
-        static_cast<double*>(A.out)[(i - A.row_begin) * A.ld_out + j] = v;
-        if (A.symmetric && ti != tj) static_cast<double*>(A.out)[j * A.ld_out + i] = v;
-    }
+    po_store_pair<OUT>(A, i, j, v, po_tile_mirrors(A, ti, tj));
 }
 
 }  // namespace
@@ -174,24 +152,15 @@ int po_launch_ranks(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq,
 
 int po_launch_kt(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, const po_tile_args& a,
                  uint64_t* tiles) {
-    const uint32_t T = (uint32_t)((n + PT - 1) / PT);
-    uint64_t nblocks;
-    uint32_t tile_row0 = 0;
-    if (a.symmetric) {
-        nblocks = (uint64_t)T * (T + 1) / 2;
-    } else {
-        tile_row0 = (uint32_t)(a.row_begin / PT);
-        const uint32_t tile_row1 = (uint32_t)((a.row_end + PT - 1) / PT);
-        nblocks = (uint64_t)(tile_row1 - tile_row0) * T;
-    }
-    if (tiles) *tiles = nblocks;
+    (void)n; (void)dim;
+    const uint64_t nblocks = po_tile_count(a, PT);
+    if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
     if (a.out_f32)
-        hipLaunchKernelGGL(kt_tile_kernel<float>, dim3((uint32_t)nblocks), dim3(kThreads), 0, ctx->stream, d_lessrank, a, T, tile_row0);
+        hipLaunchKernelGGL(kt_tile_kernel<float>, dim3((uint32_t)nblocks), dim3(kThreads), 0, ctx->stream, d_lessrank, a);
     else
-        hipLaunchKernelGGL(kt_tile_kernel<double>, dim3((uint32_t)nblocks), dim3(kThreads), 0, ctx->stream, d_lessrank, a, T, tile_row0);
+        hipLaunchKernelGGL(kt_tile_kernel<double>, dim3((uint32_t)nblocks), dim3(kThreads), 0, ctx->stream, d_lessrank, a);
     PO_CHECK_LAUNCH("kt_tile_kernel");
-    (void)dim;
     return PO_OK;
 }

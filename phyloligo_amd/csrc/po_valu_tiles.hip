@@ -19,7 +19,7 @@
 //   ln s = (e*ln2 + logc[j]) + (r - r^2/2 + r^3/3 - r^4/4)          (abs. error < 1e-12)
 // The {invc, logc} pairs sit in LDS replicated 16x (one copy per bank quad) so that the
 // per-lane lookups of a wave never conflict.
-#include "po_internal.h"
+#include "po_tiles.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -34,26 +34,8 @@ constexpr int kTabBytes = kTabEntries * 256;            // 16 copies x 16 B per 
 constexpr int kStageDoubles = KC * (TM + TN);           // one buffer
 constexpr double LN2 = 0.693147180559945309417232121458;
 
-struct TileCoord { uint32_t ti, tj; };
 
-// linear block id -> tile of the upper triangle (tj >= ti), row major
-__device__ __forceinline__ TileCoord tri_decode(uint64_t b, uint32_t T) {
-    const double tt = 2.0 * T + 1.0;
-    uint32_t i = (uint32_t)((tt - sqrt(tt * tt - 8.0 * (double)b)) * 0.5);
-    // rows before i hold i*T - i(i-1)/2 tiles; fix the float estimate
-    auto before = [T](uint64_t r) { return r * T - r * (r - 1) / 2; };
-    while (i > 0 && before(i) > b) --i;
-    while (before((uint64_t)i + 1) <= b) ++i;
-    return {i, (uint32_t)(i + (b - before(i)))};
-}
 
-template <typename T> __device__ __forceinline__ void store_out(void* out, uint64_t idx, double v);
-template <> __device__ __forceinline__ void store_out<double>(void* out, uint64_t idx, double v) {
-    static_cast<double*>(out)[idx] = v;
-}
-template <> __device__ __forceinline__ void store_out<float>(void* out, uint64_t idx, double v) {
-    static_cast<float*>(out)[idx] = (float)v;
-}
 
 struct JsdConsts {
     uint32_t tcopy;   // LDS byte address of this lane's table copy
@@ -220,8 +202,7 @@ __device__ __forceinline__ void jsd_word(const JsdConsts& C, const double* s, in
 
 template <int METRIC, typename OUT, int VAR>
 __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, const double2* __restrict__ logtab,
-                                                                const unsigned long long* __restrict__ cls,
-                                                                uint32_t tiles_n, uint32_t tile_row0) {
+                                                                const unsigned long long* __restrict__ cls) {
     extern __shared__ __align__(16) unsigned char smem[];
     // the log table comes first so that a lane's lookup address is just (interval << 8 | copy)
     unsigned char* tab = smem;                                          // JSD only, kTabBytes
@@ -231,13 +212,7 @@ __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, 
     const uint32_t tx = t & 15, ty = t >> 4;
 
     uint32_t ti, tj;
-    if (A.symmetric) {
-        const TileCoord c = tri_decode(blockIdx.x, tiles_n);
-        ti = c.ti; tj = c.tj;
-    } else {
-        ti = tile_row0 + blockIdx.x / tiles_n;
-        tj = blockIdx.x % tiles_n;
-    }
+    po_tile_coords(A, TM, blockIdx.x, ti, tj);
     if (METRIC == PO_JSD && cls != nullptr) {          // tiles of equal-total record blocks belong to po_jsd_lut.hip
         const unsigned long long c = cls[ti];
         if (c != 0 && cls[tj] == c) return;
@@ -330,7 +305,7 @@ __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, 
         ei[ia] = st0[i];
         wi[ia] = st1[i];
     }
-    const bool mirror = A.symmetric && (ti != tj);
+    const bool mirror = po_tile_mirrors(A, ti, tj);
 #pragma unroll
     for (int ib = 0; ib < 8; ++ib) {
         const uint64_t j = j0 + 32 * (ib >> 1) + 2 * tx + (ib & 1);
@@ -339,7 +314,7 @@ __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, 
 #pragma unroll
         for (int ia = 0; ia < 8; ++ia) {
             const uint64_t i = i0 + ty * 8 + ia;
-            if (i < A.row_begin || i >= A.row_end) continue;
+            if (!po_in_block(A, i, j)) continue;
             double v;
             if (METRIC == PO_JSD) {
                 v = 0.5 * (ei[ia] + ej - acc[ia][ib]) + (0.5 * LN2) * (wi[ia] + wj);
@@ -348,25 +323,15 @@ __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, 
                 v = acc[ia][ib] / (wi[ia] + wj);                     // 0/0 -> NaN as SciPy gives
             }
             if (i == j) v = 0.0;                                     // metric(x,x) / squareform diagonal
-            store_out<OUT>(A.out, (i - A.row_begin) * A.ld_out + j, v);
-            if (mirror) store_out<OUT>(A.out, j * A.ld_out + i, v);
+            po_store_pair<OUT>(A, i, j, v, mirror);
         }
     }
 }
 
 template <int METRIC, int VAR>
 int launch_metric(po_ctx* ctx, const po_tile_args& a, const unsigned long long* cls, uint64_t* tiles) {
-    const uint32_t T = (uint32_t)((a.n + TN - 1) / TN);
-    uint64_t nblocks;
-    uint32_t tile_row0 = 0;
-    if (a.symmetric) {
-        nblocks = (uint64_t)T * (T + 1) / 2;
-    } else {
-        tile_row0 = (uint32_t)(a.row_begin / TM);
-        const uint32_t tile_row1 = (uint32_t)((a.row_end + TM - 1) / TM);
-        nblocks = (uint64_t)(tile_row1 - tile_row0) * T;
-    }
-    if (tiles) *tiles = nblocks;
+    const uint64_t nblocks = po_tile_count(a, TM);
+    if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
     const size_t shmem = 2 * kStageDoubles * sizeof(double) + (METRIC == PO_JSD ? kTabBytes : 0);
@@ -374,11 +339,11 @@ int launch_metric(po_ctx* ctx, const po_tile_args& a, const unsigned long long* 
     if (a.out_f32) {
         auto k = valu_tile_kernel<METRIC, float, VAR>;
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, tab, cls, T, tile_row0);
+        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, tab, cls);
     } else {
         auto k = valu_tile_kernel<METRIC, double, VAR>;
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, tab, cls, T, tile_row0);
+        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, tab, cls);
     }
     PO_CHECK_LAUNCH("valu_tile_kernel");
     return PO_OK;

@@ -1,10 +1,24 @@
-"""Sharding of the path over the GPUs of one node (one process per GPU).
+"""Sharding of the path over the GPUs of one node (one process per GPU, torch.distributed / RCCL).
 
 Reference analogue: even row slices handed to joblib workers with the whole frequency matrix
 visible to each (gen_even_slices, /root/reference/phylopackage/bin/phyloligo.py:424,516).
-Here: contigs are split into contiguous row blocks; stage 1 runs on each rank's own contigs,
-ONE all-gather moves the exact integer count matrix (RCCL over xGMI), then every rank computes
-rows [lo,hi) x all columns of the matrix with no further exchange.
+
+Here contigs are split into contiguous, tile-aligned row blocks R_0..R_{G-1}.  Stage 1 runs on each
+rank's own contigs, ONE all-gather moves the exact integer count matrix (the only exchange the path
+needs), then the upper triangle of the block grid is dealt out like a round-robin tournament so that
+every unordered pair of records is evaluated exactly once in the whole job:
+
+  rank g computes   R_g x R_g                      (triangular, mirrored inside its own slab)
+                    R_g x R_{(g+s) mod G}          s = 1 .. ceil(G/2)-1   (+ the transposed block,
+                                                   kept in a mirror buffer owned by rank g+s)
+  and, for even G,  half of R_g x R_{g+G/2}        (the two partners split that block by rows of the
+                                                   lower-numbered one)
+
+Every rank does (N/G)^2 * G/2 pair evaluations: the same total as one GPU using symmetry, perfectly
+balanced, no collective inside the compute.  After it, every matrix entry (i,j) and (j,i) is resident
+in HBM on the rank that evaluated the pair; `complete_rows` is the optional second exchange (point to
+point over xGMI) that sends each mirror buffer to the rank whose row slab it belongs to, for
+consumers that want row-complete slabs (e.g. writing the .mat).
 """
 import numpy as np
 
@@ -14,6 +28,7 @@ class RowBlockPlan:
         self.n, self.world = int(n), int(world)
         per = -(-self.n // self.world)
         per = -(-per // align) * align            # tile aligned so no two ranks share a tile row
+        self.align = align
         self.bounds = [min(self.n, r * per) for r in range(self.world + 1)]
         self.bounds[-1] = self.n
 
@@ -21,11 +36,11 @@ class RowBlockPlan:
         return self.bounds[rank], self.bounds[rank + 1]
 
     def describe(self):
-        return "row blocks x all columns, %d rank(s), bounds %s" % (self.world, self.bounds if self.world <= 8 else "...")
+        return "tournament over %d row block(s), bounds %s" % (self.world, self.bounds if self.world <= 8 else "...")
 
+    # ---- the single exchange of the path: exact count matrix to every rank ------------------------
     def all_gather_profiles(self, my_counts, my_totals, dist):
-        """counts[n, dim] int32 / totals[n] int64 on every rank.  Row blocks are ragged, so the
-        exchange is an all_gather into per-rank views of the final tensors."""
+        """counts[n, dim] int32 / totals[n] int64 on every rank."""
         import torch
         if dist is None or self.world == 1:
             return my_counts, my_totals
@@ -53,3 +68,98 @@ class RowBlockPlan:
             counts[lo:hi] = gc[r * per:r * per + (hi - lo)]
             totals[lo:hi] = gt[r * per:r * per + (hi - lo)]
         return counts, totals
+
+    # ---- tournament schedule ---------------------------------------------------------------------------
+    def _half(self, a):
+        """split point of R_a for the half blocks of an even world (tile aligned)"""
+        lo, hi = self.rows(a)
+        mid = lo + (-(-((hi - lo) // 2) // self.align)) * self.align
+        return min(mid, hi)
+
+    def work(self, rank):
+        """List of (rows, cols, kind, peer) this rank evaluates.  kind: 'diag' (triangular, no peer),
+        'full' / 'half' (rectangular; the transposed block belongs to `peer`'s slab)."""
+        G, g = self.world, rank
+        lo, hi = self.rows(g)
+        items = [((lo, hi), (lo, hi), "diag", None)]
+        for s in range(1, (G + 1) // 2):
+            p = (g + s) % G
+            items.append(((lo, hi), self.rows(p), "full", p))
+        if G % 2 == 0 and G > 1:
+            p = (g + G // 2) % G
+            a = min(g, p)
+            mid = self._half(a)
+            if g == a:      # lower partner: first half of its own rows x all of the partner's columns
+                items.append(((lo, mid), self.rows(p), "half", p))
+            else:           # upper partner: all of its rows x second half of the partner's rows (as columns)
+                items.append(((lo, hi), (mid, self.rows(a)[1]), "half", p))
+        return [it for it in items if it[0][1] > it[0][0] and it[1][1] > it[1][0]]
+
+    def pair_evaluations(self, rank):
+        tot = 0
+        for (r0, r1), (c0, c1), kind, _ in self.work(rank):
+            tot += (r1 - r0) * (r1 - r0 + 1) // 2 if kind == "diag" else (r1 - r0) * (c1 - c0)
+        return tot
+
+    def allocate(self, rank, device, dtype):
+        """Row slab [rows_g, n] and one mirror buffer per rectangular block."""
+        import torch
+        lo, hi = self.rows(rank)
+        slab = torch.empty((hi - lo, self.n), dtype=dtype, device=device)
+        mirrors = []
+        for (r0, r1), (c0, c1), kind, peer in self.work(rank):
+            mirrors.append(None if kind == "diag" else torch.empty((c1 - c0, r1 - r0), dtype=dtype, device=device))
+        return slab, mirrors
+
+    def blocks(self, rank, slab, mirrors):
+        """Block list for Context.pairwise_blocks."""
+        lo, _ = self.rows(rank)
+        out = []
+        for ((r0, r1), (c0, c1), kind, peer), m in zip(self.work(rank), mirrors):
+            view = slab[r0 - lo:r1 - lo, c0:c1]
+            if kind == "diag":
+                out.append({"rows": (r0, r1), "cols": (c0, c1), "out": view, "triangular": True})
+            else:
+                out.append({"rows": (r0, r1), "cols": (c0, c1), "out": view, "mirror": m})
+        return out
+
+    def compute(self, ctx, counts, totals, metric, rank, slab, mirrors, want_stats=False, table_path=True):
+        return ctx.pairwise_blocks(counts, totals, metric, self.blocks(rank, slab, mirrors), dtype=slab.dtype,
+                                   want_stats=want_stats, table_path=table_path)
+
+    def complete_rows(self, rank, slab, mirrors, dist):
+        """Second, optional exchange: send every mirror buffer to the rank whose slab it completes and
+        place the received ones.  Point to point (RCCL send/recv over xGMI), all transfers in flight at once."""
+        import torch
+        lo, hi = self.rows(rank)
+        if dist is None or self.world == 1:
+            return slab
+        ops, recvs = [], []
+        for ((r0, r1), (c0, c1), kind, peer), m in zip(self.work(rank), mirrors):
+            if kind != "diag":
+                ops.append(dist.P2POp(dist.isend, m, peer))
+        for src in range(self.world):
+            if src == rank:
+                continue
+            for (r0, r1), (c0, c1), kind, peer in self.work(src):
+                if kind != "diag" and peer == rank:      # src evaluated rows [r0,r1) x cols [c0,c1) subset of my rows
+                    buf = torch.empty((c1 - c0, r1 - r0), dtype=slab.dtype, device=slab.device)
+                    ops.append(dist.P2POp(dist.irecv, buf, src))
+                    recvs.append((buf, c0 - lo, c1 - lo, r0, r1))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for buf, a0, a1, b0, b1 in recvs:
+            slab[a0:a1, b0:b1] = buf
+        return slab
+
+
+def assemble_virtual(plan, slabs, mirrors_by_rank):
+    """Single-process stand-in for complete_rows (tests, one GPU): place every mirror buffer into the
+    slab of the rank that owns those rows and return the full matrix."""
+    import torch
+    for g in range(plan.world):
+        for ((r0, r1), (c0, c1), kind, peer), m in zip(plan.work(g), mirrors_by_rank[g]):
+            if kind != "diag":
+                plo, _ = plan.rows(peer)
+                slabs[peer][c0 - plo:c1 - plo, r0:r1] = m
+    return torch.cat(slabs, dim=0)

@@ -47,6 +47,54 @@ def test_all_gather_profiles_world2(n):
     assert spans[0][0] == 0 and spans[-1][1] == n and spans[0][1] == spans[1][0]
 
 
+def _exchange_worker(rank, world, port, n, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = RowBlockPlan(n, world, align=16)
+        rng = np.random.default_rng(5)
+        m = rng.random((n, n))
+        full = torch.from_numpy(m + m.T)                      # the symmetric matrix the kernels would produce
+        lo, hi = plan.rows(rank)
+        slab = torch.full((hi - lo, n), float("nan"), dtype=torch.float64)
+        mirrors = []
+        for (r0, r1), (c0, c1), kind, peer in plan.work(rank):   # stand-in for plan.compute()
+            slab[r0 - lo:r1 - lo, c0:c1] = full[r0:r1, c0:c1]
+            mirrors.append(None if kind == "diag" else full[r0:r1, c0:c1].T.contiguous())
+        plan.complete_rows(rank, slab, mirrors, dist)
+        ret[rank] = bool(torch.equal(slab, full[lo:hi]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 100), (3, 100), (4, 131)])
+def test_complete_rows_exchange(world, n):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_exchange_worker, args=(world, _free_port(), n, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world))
+
+
+def test_tournament_covers_every_pair_once():
+    for n in (300, 1024, 1000):
+        for world in (1, 2, 3, 4, 5, 8):
+            plan = RowBlockPlan(n, world)
+            cover = np.zeros((n, n), dtype=np.int32)
+            for g in range(world):
+                for (r0, r1), (c0, c1), kind, peer in plan.work(g):
+                    if kind == "diag":
+                        cover[r0:r1, c0:c1] += 1
+                    else:
+                        assert peer is not None and peer != g
+                        cover[r0:r1, c0:c1] += 1
+                        cover[c0:c1, r0:r1] += 1
+            assert (cover == 1).all(), (n, world)
+    plan = RowBlockPlan(141312, 8)
+    ev = [plan.pair_evaluations(g) for g in range(8)]
+    assert max(ev) / (sum(ev) / 8) < 1.001 and sum(ev) == 141312 * 141313 // 2
+
+
 def test_row_blocks_partition():
     for n in (1, 127, 128, 129, 50000, 70711, 200000):
         for world in (1, 2, 3, 4, 8):

@@ -181,3 +181,35 @@ def test_jsd_equal_total_table_path_and_mixed_tiles(ctx):
     assert st["kernel_id"] == 1 and np.array_equal(gen2, gen)
     o2c, o2t = po.compute_counts(fixed, "1111", "both")
     np.testing.assert_allclose(lut, po.pairwise_block(po.counts_to_frequencies(o2c, o2t), "JSD"), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("metric", ["JSD", "Eucl", "BC", "KT"])
+def test_tournament_blocks_virtual_ranks(ctx, metric, world):
+    """The multi-GPU work lists, run rank after rank on one GPU through po_pairwise_blocks_dev: the
+    assembled slabs (after the mirror placement that complete_rows does over RCCL) equal the
+    single-GPU matrix bit for bit."""
+    import torch
+    from phyloligo_amd.dist import RowBlockPlan, assemble_virtual
+    n = 700 if metric != "KT" else 300
+    contigs = _random_assembly(n - 3, 77 + world, lo=300, hi=1500) + [b"", b"ACGTNNNNACGTAC", b"ACGTACGTAC"]
+    if metric == "JSD":      # a stretch of equal-total records so that both JSD kernels take part
+        contigs[128:384] = _random_assembly(256, 5, lo=900, hi=901)
+    seq, offsets = pack(contigs)
+    dseq = torch.from_numpy(seq).cuda()
+    doff = torch.from_numpy(offsets.astype(np.int64)).cuda()
+    pattern = "1111" if metric != "KT" else "111"
+    counts, totals = ctx.count_profiles(dseq, doff, pattern, "both")
+    full = ctx.pairwise(counts, totals, metric)
+    plan = RowBlockPlan(n, world)
+    slabs, mirrors = [], []
+    for g in range(world):
+        slab, mir = plan.allocate(g, counts.device, torch.float64)
+        slab.fill_(float("nan"))
+        plan.compute(ctx, counts, totals, metric, g, slab, mir)
+        slabs.append(slab)
+        mirrors.append(mir)
+    got = assemble_virtual(plan, slabs, mirrors)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.isnan(got), torch.isnan(full))
+    assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(full, nan=-1.0))
