@@ -146,8 +146,9 @@ class RowBlockPlan:
                     buf = torch.empty((c1 - c0, r1 - r0), dtype=slab.dtype, device=slab.device)
                     ops.append(dist.P2POp(dist.irecv, buf, src))
                     recvs.append((buf, c0 - lo, c1 - lo, r0, r1))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        if ops:                                   # a rank with an empty row block has nothing to move
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
         for buf, a0, a1, b0, b1 in recvs:
             slab[a0:a1, b0:b1] = buf
         return slab
