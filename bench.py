@@ -61,10 +61,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PO_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo collectives -- lets the N>1 code path be run on
+    # a one-GPU box (numbers are meaningless then); the real run is one rank per GPU over RCCL.
+    rehearsal = os.environ.get("PO_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
@@ -86,7 +94,11 @@ def main():
     my_counts, my_totals = ctx.count_profiles(d_seq, d_off, args.pattern, "both")
     torch.cuda.synchronize(dev)
     stage1_ms = (time.perf_counter() - t0) * 1e3
-    counts, totals = plan.all_gather_profiles(my_counts, my_totals, dist)
+    if rehearsal and dist is not None:
+        counts, totals = plan.all_gather_profiles(my_counts.cpu(), my_totals.cpu(), dist)
+        counts, totals = counts.to(dev), totals.to(dev)
+    else:
+        counts, totals = plan.all_gather_profiles(my_counts, my_totals, dist)
     dim = counts.shape[1]
     rows = hi - lo
     slab, mirrors = plan.allocate(rank, dev, torch.float64)     # this rank's rows x all columns (+ mirror blocks)
@@ -111,7 +123,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

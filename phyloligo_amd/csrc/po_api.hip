@@ -291,6 +291,10 @@ static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
         rc = po_buf_reserve(ctx, &ctx->ws_aux, po_jsd_lut_workspace(n, dim));
         if (rc) return rc;
     }
+    if (metric == PO_EUCL) {
+        rc = po_buf_reserve(ctx, &ctx->ws_aux, po_gram_i8_workspace(n, dim));
+        if (rc) return rc;
+    }
     return PO_OK;
 }
 
@@ -346,9 +350,17 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     // ---- prep: working layout + per-row terms (once) ----
     uint32_t* lessrank = nullptr;
     const unsigned long long* cls = nullptr;
+    const uint32_t* i8flag = nullptr;
+    if (metric == PO_EUCL && d_counts && !(flags & PO_FLAG_NO_TABLE_PATH)) {
+        // profiles that fit int8 go through the exact integer MFMA kernel; both tile kernels are launched
+        // and the device-side flag decides which one does the work (and whether the float64 operand
+        // matrix is built at all)
+        rc = po_launch_gram_i8_prep(ctx, d_counts, d_totals, n, dim, npad, ctx->ws_aux.p, &i8flag);
+        if (rc) return rc;
+    }
     if (metric == PO_EUCL || metric == PO_JSD || metric == PO_BC) {
         rc = d_freq ? po_launch_prep_freq(ctx, d_freq, n, dim, npad, ft)
-                    : po_launch_prep(ctx, d_counts, d_totals, n, dim, npad, ft);
+                    : po_launch_prep(ctx, d_counts, d_totals, n, dim, npad, ft, i8flag);
         if (rc) return rc;
     }
     if (metric == PO_JSD || metric == PO_BC) {
@@ -361,7 +373,7 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     }
     if (rc) return rc;
     if (metric == PO_EUCL || metric == PO_SC) {
-        rc = po_launch_gram_norms(ctx, ft, dim, npad, rowstat);
+        rc = po_launch_gram_norms(ctx, ft, dim, npad, rowstat, i8flag);
         if (rc) return rc;
     }
     if (metric == PO_JSD && d_counts && !(flags & PO_FLAG_NO_TABLE_PATH)) {
@@ -392,6 +404,8 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         a.mirror = k.triangular ? k.out : k.mirror;
         a.ld_mirror = k.triangular ? k.ld_out : k.ld_mirror;
         a.out_f32 = (out_dtype == PO_F32);
+        static const bool dbg_no_mirror = getenv("PO_DEBUG_NO_MIRROR") != nullptr;   // timing experiments only
+        if (dbg_no_mirror) a.mirror = nullptr;
         switch (metric) {
             case PO_JSD:
                 if (cls) {
@@ -402,8 +416,15 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
                 kid = cls ? PO_KERNEL_LUT_JSD : PO_KERNEL_VALU_JSD;
                 break;
             case PO_BC: rc = po_launch_valu_tiles(ctx, PO_BC, a, nullptr, &tiles); kid = PO_KERNEL_VALU_BC; break;
-            case PO_EUCL: rc = po_launch_gram_f64(ctx, PO_EUCL, a, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
-            case PO_SC: rc = po_launch_gram_f64(ctx, PO_SC, a, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
+            case PO_EUCL:
+                if (i8flag) {
+                    rc = po_launch_gram_i8_tiles(ctx, a, ctx->ws_aux.p, &tiles);
+                    if (rc) return rc;
+                }
+                rc = po_launch_gram_f64(ctx, PO_EUCL, a, i8flag, i8flag ? nullptr : &tiles);
+                kid = i8flag ? PO_KERNEL_MFMA_I8_GRAM : PO_KERNEL_MFMA_F64_GRAM;
+                break;
+            case PO_SC: rc = po_launch_gram_f64(ctx, PO_SC, a, nullptr, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
             case PO_KT: rc = po_launch_kt(ctx, lessrank, n, dim, a, &tiles); kid = PO_KERNEL_VALU_KT; break;
         }
         if (rc) return rc;

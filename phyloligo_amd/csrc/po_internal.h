@@ -85,8 +85,9 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets
                     uint64_t* d_totals);
 
 // Working layout of stage 2: Ft[d][npad] = counts[n][d] / totals[n] (float64, zero padded).
+// skip_if_le127 (may be NULL): device word with the largest count; the kernel does nothing when it is <= 127
 int po_launch_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
-                   uint64_t npad, double* d_ft);
+                   uint64_t npad, double* d_ft, const uint32_t* skip_if_le127);
 int po_launch_prep_freq(po_ctx* ctx, const double* d_freq, uint64_t n, uint32_t dim, uint64_t npad, double* d_ft);
 int po_launch_freq_rowmajor(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
                             uint32_t dim, double* d_freq);
@@ -115,8 +116,14 @@ size_t po_jsd_lut_workspace(uint64_t n, uint32_t dim);
 int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
                            uint64_t npad, void* ws, const unsigned long long** cls_out);
 int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, const void* ws, uint64_t* tiles);
-int po_launch_gram_norms(po_ctx* ctx, const double* ft, uint32_t dim, uint64_t npad, double* rowstat);
-int po_launch_gram_f64(po_ctx* ctx, int metric, const po_tile_args& a, uint64_t* tiles);
+size_t po_gram_i8_workspace(uint64_t n, uint32_t dim);
+int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                           uint64_t npad, void* ws, const uint32_t** flag_out);
+int po_launch_gram_i8_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint64_t* tiles);
+int po_launch_gram_norms(po_ctx* ctx, const double* ft, uint32_t dim, uint64_t npad, double* rowstat, const uint32_t* skip_if_le127);
+// i8flag (may be NULL): device word holding the largest count; the float64 kernel leaves the matrix to the
+// int8 kernel when it is <= 127
+int po_launch_gram_f64(po_ctx* ctx, int metric, const po_tile_args& a, const uint32_t* i8flag, uint64_t* tiles);
 int po_logtab_init(po_ctx* ctx);
 
 // KT / SC helpers.  Order statistics of every record, from counts (uint32) or frequencies (float64):

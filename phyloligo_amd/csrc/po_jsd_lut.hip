@@ -15,6 +15,8 @@
 // equal and non-zero, every other tile is left to valu_tile_kernel<JSD>, which skips the marked ones.
 #include "po_tiles.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int TM = 128, TN = 128;
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void prep_counts_kernel(const uint32_t* __rest
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(&blkmax, mx);
     __syncthreads();
-    if (threadIdx.x == 0 && blkmax) atomicMax(maxcount, blkmax);
+    if (threadIdx.x == 0 && blkmax > *maxcount) atomicMax(maxcount, blkmax);   // racy pre-check skips redundant atomics
     for (uint32_t r = ty; r < 64; r += 4)
         if (d0 + r < ((dim + 7u) & ~7u) && n0 + tx < npad) ct[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r];
 }
@@ -86,10 +88,13 @@ __device__ __forceinline__ double lds_read_f64(uint32_t) { return 0.0; }
 __device__ __forceinline__ void glds16(const void*, void*) {}
 #endif
 
-template <typename OUT>
-__global__ __launch_bounds__(kThreads, 2) void jsd_lut_tile_kernel(po_tile_args A, const uint32_t* __restrict__ ct,
-                                                                   const double* __restrict__ lut,
-                                                                   const unsigned long long* __restrict__ cls) {
+// RPT rows per lane: 8 -> 256 lanes per 128 x 128 tile, 4 -> 512 lanes (more waves per SIMD to hide the
+// LDS round trips; the table is shared by twice as many waves).
+template <typename OUT, int RPT>
+__global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void jsd_lut_tile_kernel(po_tile_args A, const uint32_t* __restrict__ ct,
+                                                                                  const double* __restrict__ lut,
+                                                                                  const unsigned long long* __restrict__ cls) {
+    constexpr int NT = 2048 / RPT;                                               // lanes per workgroup
     extern __shared__ __align__(16) unsigned char smem[];
     double* tab = reinterpret_cast<double*>(smem);                               // [128][32]
     uint32_t* stage = reinterpret_cast<uint32_t*>(smem + kLutBytes);             // [2][A: KC x 128 | B: KC x 128]
@@ -104,22 +109,30 @@ __global__ __launch_bounds__(kThreads, 2) void jsd_lut_tile_kernel(po_tile_args 
     if (ntot == 0 || cls[tj] != ntot) return;                                    // valu_tile_kernel<JSD> owns this tile
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
 
-    for (uint32_t e = t; e < kLutEntries * 32; e += kThreads) tab[e] = lut[e >> 5];
+    for (uint32_t e = t; e < kLutEntries * 32; e += NT) tab[e] = lut[e >> 5];
 
-    double acc[8][8];
+    double acc[RPT][8];
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+    for (int a = 0; a < RPT; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
 
-    // staging: one LDS-DMA instruction moves 64 lanes x 16 B = two 512-byte word rows; wave w takes
-    // words 2w, 2w+1 of the A block and of the B block
+    // staging: one LDS-DMA instruction moves 64 lanes x 16 B = two 512-byte word rows.  With 4 waves
+    // each wave takes words 2w, 2w+1 of the A block and of the B block; with 8 waves, waves 0-3 take
+    // the A block and waves 4-7 the B block.
     auto gstage = [&](uint32_t k0, uint32_t buf) {
-        const uint32_t k = wave * 2 + (lane >> 5);
+        const uint32_t w4 = wave & 3;
+        const uint32_t k = w4 * 2 + (lane >> 5);
         const uint32_t* row = ct + (uint64_t)(k0 + k) * A.npad + (lane & 31) * 4;
-        uint32_t* dst = stage + buf * kStageWords + wave * 2 * TM;
-        glds16(row + i0, dst);
-        glds16(row + j0, dst + KC * TM);
+        uint32_t* dst = stage + buf * kStageWords + w4 * 2 * TM;
+        if (RPT == 8) {
+            glds16(row + i0, dst);
+            glds16(row + j0, dst + KC * TM);
+        } else if (wave < 4) {
+            glds16(row + i0, dst);
+        } else {
+            glds16(row + j0, dst + KC * TM);
+        }
     };
     gstage(0, 0);
     __syncthreads();
@@ -128,15 +141,18 @@ __global__ __launch_bounds__(kThreads, 2) void jsd_lut_tile_kernel(po_tile_args 
     uint32_t cur = 0;
     for (uint32_t k0 = 0; k0 < A.dim; k0 += KC) {
         if (k0 + KC < A.dim) gstage(k0 + KC, cur ^ 1);
-        const uint32_t* sA = stage + cur * kStageWords + ty * 8;
+        const uint32_t* sA = stage + cur * kStageWords + ty * RPT;
         const uint32_t* sB = stage + cur * kStageWords + KC * TM + tx * 4;
 #pragma unroll 2
         for (int k = 0; k < KC; ++k) {
-            const uint4 a0 = *reinterpret_cast<const uint4*>(sA + k * TM);
-            const uint4 a1 = *reinterpret_cast<const uint4*>(sA + k * TM + 4);
+            uint32_t a[RPT];
+#pragma unroll
+            for (int q = 0; q < RPT / 4; ++q) {
+                const uint4 av = *reinterpret_cast<const uint4*>(sA + k * TM + 4 * q);
+                a[4 * q] = av.x; a[4 * q + 1] = av.y; a[4 * q + 2] = av.z; a[4 * q + 3] = av.w;
+            }
             const uint4 b0 = *reinterpret_cast<const uint4*>(sB + k * TN);
             const uint4 b1 = *reinterpret_cast<const uint4*>(sB + k * TN + 64);
-            const uint32_t a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             const uint32_t b[8] = {b0.x + tcopy, b0.y + tcopy, b0.z + tcopy, b0.w + tcopy,
                                    b1.x + tcopy, b1.y + tcopy, b1.z + tcopy, b1.w + tcopy};
             // the 8 lookups of register-block row ia+1 are in flight while row ia is accumulated
@@ -144,8 +160,8 @@ __global__ __launch_bounds__(kThreads, 2) void jsd_lut_tile_kernel(po_tile_args 
 #pragma unroll
             for (int ib = 0; ib < 8; ++ib) tv[0][ib] = lds_read_f64(a[0] + b[ib]);
 #pragma unroll
-            for (int ia = 0; ia < 8; ++ia) {
-                if (ia + 1 < 8) {
+            for (int ia = 0; ia < RPT; ++ia) {
+                if (ia + 1 < RPT) {
 #pragma unroll
                     for (int ib = 0; ib < 8; ++ib) tv[(ia + 1) & 1][ib] = lds_read_f64(a[ia + 1] + b[ib]);
                 }
@@ -161,9 +177,9 @@ __global__ __launch_bounds__(kThreads, 2) void jsd_lut_tile_kernel(po_tile_args 
     const double inv_n = 1.0 / (double)ntot;
     const double two_ln_n = 2.0 * log((double)ntot);
     const double* st0 = A.rowstat;
-    double ei[8];
+    double ei[RPT];
 #pragma unroll
-    for (int ia = 0; ia < 8; ++ia) ei[ia] = st0[i0 + ty * 8 + ia];
+    for (int ia = 0; ia < RPT; ++ia) ei[ia] = st0[i0 + ty * RPT + ia];
     const bool mirror = po_tile_mirrors(A, ti, tj);
 #pragma unroll
     for (int ib = 0; ib < 8; ++ib) {
@@ -171,8 +187,8 @@ __global__ __launch_bounds__(kThreads, 2) void jsd_lut_tile_kernel(po_tile_args 
         if (j >= A.n) continue;
         const double ej = st0[j];
 #pragma unroll
-        for (int ia = 0; ia < 8; ++ia) {
-            const uint64_t i = i0 + ty * 8 + ia;
+        for (int ia = 0; ia < RPT; ++ia) {
+            const uint64_t i = i0 + ty * RPT + ia;
             if (!po_in_block(A, i, j)) continue;
             const double S = fma(acc[ia][ib], inv_n, -two_ln_n);
             double v = fmax(0.5 * (ei[ia] + ej - S) + LN2, 0.0);
@@ -227,10 +243,13 @@ int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, cons
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
     const size_t shmem = kLutBytes + 2 * kStageWords * sizeof(uint32_t);
+    static const int rpt = getenv("PO_LUT_RPT") ? atoi(getenv("PO_LUT_RPT")) : 4;
     if (a.out_f32)
-        hipLaunchKernelGGL(jsd_lut_tile_kernel<float>, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, ct, lut, cls);
+        hipLaunchKernelGGL((jsd_lut_tile_kernel<float, 8>), dim3((uint32_t)nblocks), dim3(256), shmem, ctx->stream, a, ct, lut, cls);
+    else if (rpt == 4)
+        hipLaunchKernelGGL((jsd_lut_tile_kernel<double, 4>), dim3((uint32_t)nblocks), dim3(512), shmem, ctx->stream, a, ct, lut, cls);
     else
-        hipLaunchKernelGGL(jsd_lut_tile_kernel<double>, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, ct, lut, cls);
+        hipLaunchKernelGGL((jsd_lut_tile_kernel<double, 8>), dim3((uint32_t)nblocks), dim3(256), shmem, ctx->stream, a, ct, lut, cls);
     PO_CHECK_LAUNCH("jsd_lut_tile_kernel");
     return PO_OK;
 }

@@ -213,3 +213,34 @@ def test_tournament_blocks_virtual_ranks(ctx, metric, world):
     torch.cuda.synchronize()
     assert torch.equal(torch.isnan(got), torch.isnan(full))
     assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(full, nan=-1.0))
+
+
+def test_eucl_int8_and_float64_mfma_paths(ctx):
+    """Profiles <= 127 take the exact int8-MFMA kernel, larger counts the float64-MFMA kernel; both against
+    the oracle, plus the forced general path on the small-count data."""
+    from oracle import phyloligo_oracle as po
+    small = _random_assembly(333, 21, lo=200, hi=3000) + [b"", b"ACGTACGTAC"]
+    small.append(small[7])
+    big = _random_assembly(40, 22, lo=30000, hi=60000) + small[:50]          # counts far above 127
+    for contigs in (small, big):
+        seq, offsets = pack(contigs)
+        counts, totals = ctx.count_profiles(seq, offsets, "1111", "both")
+        oc, ot = po.compute_counts(contigs, "1111", "both")
+        want = po.pairwise_block(po.counts_to_frequencies(oc, ot), "Eucl")
+        got, st = ctx.pairwise(counts, totals, "Eucl", want_stats=True)
+        assert st["kernel_id"] == 4
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+        assert np.array_equal(got, got.T) and np.all(np.diag(got) == 0.0)
+        gen = ctx.pairwise(counts, totals, "Eucl", table_path=False)
+        np.testing.assert_allclose(gen, want, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(ctx.pairwise(counts, totals, "Eucl", symmetric=False), want, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(ctx.pairwise(counts, totals, "Eucl", row_begin=11, row_end=77), want[11:77],
+                                   rtol=RTOL, atol=ATOL)
+    assert counts.max() > 127
+    seq, offsets = pack(small)
+    counts, totals = ctx.count_profiles(seq, offsets, "1111", "both")
+    assert counts.max() <= 127
+    got = ctx.pairwise(counts, totals, "Eucl")
+    assert got[7, len(small) - 1] == 0.0                     # duplicate records: exactly 0, like (a-b)^2
+    got32 = ctx.pairwise(counts, totals, "Eucl", dtype="float32")
+    np.testing.assert_array_equal(got32, got.astype(np.float32))
