@@ -142,7 +142,7 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void jsd_lut_tile_ker
     for (uint32_t k0 = 0; k0 < A.dim; k0 += KC) {
         if (k0 + KC < A.dim) gstage(k0 + KC, cur ^ 1);
         const uint32_t* sA = stage + cur * kStageWords + ty * RPT;
-        const uint32_t* sB = stage + cur * kStageWords + KC * TM + tx * 4;
+        const uint32_t* sB = stage + cur * kStageWords + KC * TM + tx * 2;
 #pragma unroll 2
         for (int k = 0; k < KC; ++k) {
             uint32_t a[RPT];
@@ -151,10 +151,12 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void jsd_lut_tile_ker
                 const uint4 av = *reinterpret_cast<const uint4*>(sA + k * TM + 4 * q);
                 a[4 * q] = av.x; a[4 * q + 1] = av.y; a[4 * q + 2] = av.z; a[4 * q + 3] = av.w;
             }
-            const uint4 b0 = *reinterpret_cast<const uint4*>(sB + k * TN);
-            const uint4 b1 = *reinterpret_cast<const uint4*>(sB + k * TN + 64);
-            const uint32_t b[8] = {b0.x + tcopy, b0.y + tcopy, b0.z + tcopy, b0.w + tcopy,
-                                   b1.x + tcopy, b1.y + tcopy, b1.z + tcopy, b1.w + tcopy};
+            uint32_t b[8];                                 // columns 32*q + 2*tx + {0,1}, table base folded in
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint2 bv = *reinterpret_cast<const uint2*>(sB + k * TN + 32 * q);
+                b[2 * q] = bv.x + tcopy; b[2 * q + 1] = bv.y + tcopy;
+            }
             // the 8 lookups of register-block row ia+1 are in flight while row ia is accumulated
             double tv[2][8];
 #pragma unroll
@@ -180,22 +182,20 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void jsd_lut_tile_ker
     double ei[RPT];
 #pragma unroll
     for (int ia = 0; ia < RPT; ++ia) ei[ia] = st0[i0 + ty * RPT + ia];
-    const bool mirror = po_tile_mirrors(A, ti, tj);
 #pragma unroll
     for (int ib = 0; ib < 8; ++ib) {
-        const uint64_t j = j0 + 64 * (ib >> 2) + 4 * tx + (ib & 3);
-        if (j >= A.n) continue;
+        const uint64_t j = min(j0 + 32 * (ib >> 1) + 2 * tx + (ib & 1), A.npad - 1);
         const double ej = st0[j];
 #pragma unroll
         for (int ia = 0; ia < RPT; ++ia) {
             const uint64_t i = i0 + ty * RPT + ia;
-            if (!po_in_block(A, i, j)) continue;
             const double S = fma(acc[ia][ib], inv_n, -two_ln_n);
             double v = fmax(0.5 * (ei[ia] + ej - S) + LN2, 0.0);
             if (i == j) v = 0.0;
-            po_store_pair<OUT>(A, i, j, v, mirror);
+            acc[ia][ib] = v;
         }
     }
+    po_store_block<OUT, RPT, NT>(A, ti, tj, i0, j0, tx, ty, acc, reinterpret_cast<double*>(smem));
 }
 
 }  // namespace

@@ -56,4 +56,66 @@ __device__ __forceinline__ void po_store_pair(const po_tile_args& A, uint64_t i,
 __device__ __forceinline__ bool po_tile_mirrors(const po_tile_args& A, uint32_t ti, uint32_t tj) {
     return A.mirror != nullptr && !(A.triangular && ti == tj);
 }
+// ---- register-block epilogue of the VALU tile kernels -------------------------------------------------
+// Lane (tx, ty) of an NT-lane workgroup holds v[ia][ib] for record rows i0 + ty*RPT + ia and record
+// columns j0 + 32*(ib>>1) + 2*tx + (ib&1).  The tile goes out as 16-byte stores along rows (16 lanes =
+// 256 contiguous bytes); the mirrored tile is transposed through LDS, 32 columns at a time, so that it
+// too leaves as full contiguous row segments (one wave = one 1 KiB row piece) instead of 64-byte crumbs.
+constexpr int kMirrorLdsStride = 130;                                 // doubles per transposed row (128 + pad)
+constexpr int kMirrorLdsBytes = 32 * kMirrorLdsStride * 8;           // 33 280 B of LDS scratch
+
+template <typename OUT, int RPT, int NT>
+__device__ __forceinline__ void po_store_block(const po_tile_args& A, uint32_t ti, uint32_t tj, uint64_t i0, uint64_t j0,
+                                               uint32_t tx, uint32_t ty, const double (&v)[RPT][8], double* lds) {
+    OUT* out = static_cast<OUT*>(A.out);
+    const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
+    // ---- the tile itself ----
+    const bool vec_out = sizeof(OUT) == 8 && (A.ld_out & 1) == 0 && ((j0 - A.col_begin) & 1) == 0 &&
+                         (reinterpret_cast<uintptr_t>(A.out) & 15) == 0 && j0 >= A.col_begin;
+#pragma unroll
+    for (int ia = 0; ia < RPT; ++ia) {
+        const uint64_t i = i0 + ty * RPT + ia;
+        if (i < A.row_begin || i >= n_rows) continue;
+        OUT* row = out + (i - A.row_begin) * A.ld_out;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t j = j0 + 32 * q + 2 * tx;
+            if (vec_out && j + 1 < n_cols) {
+                *reinterpret_cast<double2*>(row + (j - A.col_begin)) = make_double2(v[ia][2 * q], v[ia][2 * q + 1]);
+            } else {
+                if (j >= A.col_begin && j < n_cols) row[j - A.col_begin] = (OUT)v[ia][2 * q];
+                if (j + 1 >= A.col_begin && j + 1 < n_cols) row[j + 1 - A.col_begin] = (OUT)v[ia][2 * q + 1];
+            }
+        }
+    }
+    if (!po_tile_mirrors(A, ti, tj)) return;                          // uniform over the workgroup
+    // ---- the transposed tile ----
+    OUT* mir = static_cast<OUT*>(A.mirror);
+    const uint32_t t = ty * 16 + tx, lane = t & 63, wave = t >> 6;
+    const bool vec_mir = sizeof(OUT) == 8 && (A.ld_mirror & 1) == 0 && ((i0 - A.row_begin) & 1) == 0 &&
+                         (reinterpret_cast<uintptr_t>(A.mirror) & 15) == 0 && i0 >= A.row_begin;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int ia = 0; ia < RPT; ++ia) lds[(2 * tx + e) * kMirrorLdsStride + ty * RPT + ia] = v[ia][2 * q + e];
+        __syncthreads();
+        for (uint32_t jq = wave; jq < 32; jq += NT / 64) {           // one wave per transposed row
+            const uint64_t j = j0 + 32 * q + jq;
+            if (j < A.col_begin || j >= n_cols) continue;
+            const double2 w = *reinterpret_cast<const double2*>(lds + jq * kMirrorLdsStride + 2 * lane);
+            const uint64_t i = i0 + 2 * lane;
+            OUT* row = mir + (j - A.col_begin) * A.ld_mirror;
+            if (vec_mir && i + 1 < n_rows) {
+                *reinterpret_cast<double2*>(row + (i - A.row_begin)) = w;
+            } else {
+                if (i >= A.row_begin && i < n_rows) row[i - A.row_begin] = (OUT)w.x;
+                if (i + 1 >= A.row_begin && i + 1 < n_rows) row[i + 1 - A.row_begin] = (OUT)w.y;
+            }
+        }
+    }
+}
+
 #endif

@@ -305,16 +305,13 @@ __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, 
         ei[ia] = st0[i];
         wi[ia] = st1[i];
     }
-    const bool mirror = po_tile_mirrors(A, ti, tj);
 #pragma unroll
     for (int ib = 0; ib < 8; ++ib) {
-        const uint64_t j = j0 + 32 * (ib >> 1) + 2 * tx + (ib & 1);
-        if (j >= A.n) continue;
+        const uint64_t j = min(j0 + 32 * (ib >> 1) + 2 * tx + (ib & 1), A.npad - 1);
         const double ej = st0[j], wj = st1[j];
 #pragma unroll
         for (int ia = 0; ia < 8; ++ia) {
             const uint64_t i = i0 + ty * 8 + ia;
-            if (!po_in_block(A, i, j)) continue;
             double v;
             if (METRIC == PO_JSD) {
                 v = 0.5 * (ei[ia] + ej - acc[ia][ib]) + (0.5 * LN2) * (wi[ia] + wj);
@@ -323,9 +320,10 @@ __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, 
                 v = acc[ia][ib] / (wi[ia] + wj);                     // 0/0 -> NaN as SciPy gives
             }
             if (i == j) v = 0.0;                                     // metric(x,x) / squareform diagonal
-            po_store_pair<OUT>(A, i, j, v, mirror);
+            acc[ia][ib] = v;
         }
     }
+    po_store_block<OUT, 8, kThreads>(A, ti, tj, i0, j0, tx, ty, acc, reinterpret_cast<double*>(smem));
 }
 
 template <int METRIC, int VAR>
@@ -334,7 +332,7 @@ int launch_metric(po_ctx* ctx, const po_tile_args& a, const unsigned long long* 
     if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
-    const size_t shmem = 2 * kStageDoubles * sizeof(double) + (METRIC == PO_JSD ? kTabBytes : 0);
+    const size_t shmem = max((size_t)kMirrorLdsBytes, 2 * kStageDoubles * sizeof(double) + (METRIC == PO_JSD ? kTabBytes : 0));
     const double2* tab = reinterpret_cast<const double2*>(static_cast<const unsigned char*>(ctx->ws_logtab.p) + VAR * kTabBytes);
     if (a.out_f32) {
         auto k = valu_tile_kernel<METRIC, float, VAR>;
