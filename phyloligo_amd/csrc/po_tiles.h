@@ -25,18 +25,67 @@ __device__ __forceinline__ void po_tri_decode(uint64_t b, uint32_t T, uint32_t& 
     tj = (uint32_t)(i + (b - before(i)));
 }
 
+// ---- workgroup -> tile order ---------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs, each with a private 4 MiB L2 (observed, not a
+// contract: this only affects speed).  po_xcd_swizzle gives every XCD one contiguous range of the
+// logical tile order, and the logical order walks the block in bands of kBand tile rows, column by
+// column inside a band, so the tiles an XCD works on at any moment share their row operands (the band)
+// and, eight at a time, their column operand.
+constexpr uint32_t kXcds = 8;
+constexpr uint32_t kBand = 8;
+
+__device__ __forceinline__ uint64_t po_xcd_swizzle(uint64_t b, uint64_t nb) {
+    const uint64_t x = b % kXcds, q = b / kXcds;
+    const uint64_t base = nb / kXcds, rem = nb % kXcds;
+    return x * base + (x < rem ? x : rem) + q;                        // bijective for any nb
+}
+
+// logical index -> (ti, tj) inside a T x T upper triangle (tj >= ti), banded order
+__device__ __forceinline__ void po_tri_band_decode(uint64_t L, uint32_t T, uint32_t& ti, uint32_t& tj) {
+    const uint64_t S = kBand;
+    // tiles in bands < r:  r*S(S+1)/2 + S*(r*T - S*r(r+1)/2)   (bands of S full rows; the last may be short)
+    auto before = [T, S](uint64_t r) { return r * (S * (S + 1) / 2) + S * (r * T - S * r * (r + 1) / 2); };
+    const uint64_t nbands = (T + S - 1) / S;
+    // estimate by solving the quadratic, then fix up
+    const double a = 0.5 * (double)(S * S), bq = (double)S * T + 0.5 * (double)S - 0.5 * (double)(S * S);
+    double disc = bq * bq - 4.0 * a * (double)L;
+    uint64_t r = (uint64_t)((bq - sqrt(disc > 0.0 ? disc : 0.0)) / (2.0 * a));
+    if (r >= nbands) r = nbands - 1;
+    while (r > 0 && before(r) > L) --r;
+    while (r + 1 < nbands && before(r + 1) <= L) ++r;
+    uint64_t l = L - before(r);
+    const uint64_t r0 = r * S;
+    const uint64_t Se = (T - r0 < S) ? (T - r0) : S;                   // rows in this band
+    const uint64_t tri = Se * (Se + 1) / 2;
+    if (l < tri) {                                                     // the band's own triangle: column d has d+1 tiles
+        uint64_t d = (uint64_t)((sqrt(8.0 * (double)l + 1.0) - 1.0) * 0.5);
+        while (d * (d + 1) / 2 > l) --d;
+        while ((d + 1) * (d + 2) / 2 <= l) ++d;
+        ti = (uint32_t)(r0 + (l - d * (d + 1) / 2));
+        tj = (uint32_t)(r0 + d);
+    } else {
+        l -= tri;
+        ti = (uint32_t)(r0 + l % Se);
+        tj = (uint32_t)(r0 + Se + l / Se);
+    }
+}
+
 // absolute tile indices of workgroup `b`
 __device__ __forceinline__ void po_tile_coords(const po_tile_args& A, uint32_t edge, uint64_t b, uint32_t& ti, uint32_t& tj) {
     const uint32_t r0 = (uint32_t)(A.row_begin / edge), r1 = (uint32_t)((A.row_end + edge - 1) / edge);
     const uint32_t c0 = (uint32_t)(A.col_begin / edge), c1 = (uint32_t)((A.col_end + edge - 1) / edge);
     if (A.triangular) {
-        po_tri_decode(b, r1 - r0, ti, tj);
+        const uint32_t T = r1 - r0;
+        po_tri_band_decode(po_xcd_swizzle(b, (uint64_t)T * (T + 1) / 2), T, ti, tj);
         ti += r0;
         tj += r0;
     } else {
-        const uint32_t tc = c1 - c0;
-        ti = r0 + (uint32_t)(b / tc);
-        tj = c0 + (uint32_t)(b % tc);
+        const uint64_t tr = r1 - r0, tc = c1 - c0;
+        const uint64_t L = po_xcd_swizzle(b, tr * tc);
+        const uint64_t band = L / (kBand * tc), l = L % (kBand * tc);
+        const uint64_t Se = (tr - band * kBand < kBand) ? (tr - band * kBand) : kBand;
+        ti = r0 + (uint32_t)(band * kBand + l % Se);
+        tj = c0 + (uint32_t)(l / Se);
     }
 }
 
