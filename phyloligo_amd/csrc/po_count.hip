@@ -5,26 +5,26 @@
 //   (/root/reference/phylopackage/bin/phyloligo.py:124-149, :683, :601-631, :653)
 // with one byte scan: HBM-bound (1 byte per base read once, 4*4^k bytes per record written).
 //
-// Work decomposition: a record of L bases is cut into ceil(L/SPAN) chunks, one workgroup per
-// chunk (records of a 2 kb assembly are one chunk each; a 10 Mb chromosome is 2.4k chunks).
-// A workgroup stages its bytes with aligned 16-byte loads, decodes them once to 2-bit digits
-// (C=0,G=1,A=2,T=3; anything else breaks a word) in LDS, then every lane slides a 2*W-bit
-// rolling register over 16 consecutive window starts.  Both strands come out of the same
+// Work decomposition: a record of L bases is cut into ceil(L/2032) chunks, one WAVE per chunk
+// (records of a 2 kb assembly are one chunk each; a 10 Mb chromosome is 4.9k chunks spread over
+// the chip).  A wave stages its bytes with aligned 16-byte loads, decodes them once to 2-bit
+// digits (C=0,G=1,A=2,T=3; anything else breaks a word) in LDS, then every lane slides a 2*W-bit
+// rolling register over 32 consecutive window starts.  Waves never wait for each other (no
+// workgroup barrier); four of them share a workgroup only to share its launch.  Both strands come out of the same
 // pass: the forward register gives the '+' word, a second register filled from the other
 // end with complemented digits (digit XOR 1) gives the word the same window spells on the
-// reverse-complement strand.  Words go to a private LDS histogram (ds_add_u32); the W-1
-// words spanning the seq|revcomp(seq) junction of `-s both` (phyloligo.py:141) are added by
-// the chunk that holds the record's end.
+// reverse-complement strand.  Words go to a private LDS histogram (ds_add_u32) that the wave writes
+// out with 16-byte stores; the W-1 words spanning the seq|revcomp(seq) junction of `-s both`
+// (phyloligo.py:141) are added by the chunk that holds the record's end.
 #include "po_internal.h"
 
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kPerLane = 16;                       // window starts per lane
-constexpr int kTile = kThreads * kPerLane;         // 4096 staged positions carrying a window start
+constexpr int kPerLane = 32;                       // window starts per lane
+constexpr int kTile = 64 * kPerLane;               // 2048 staged positions carrying a window start, per wave
 constexpr int kSpan = kTile - 16;                  // window starts per chunk (16 B alignment slack)
-constexpr int kHalo = 48;                          // >= W-1 (31), keeps the staging a multiple of 16 B
-constexpr int kStage = kTile + kHalo;              // staged bytes per chunk
+constexpr int kStage = kTile + 64;                 // staged bytes per chunk (halo >= W-1 = 31, multiple of 16 B)
 constexpr uint32_t kMaxLdsBins = 16384;            // 64 KiB histogram; above that count in HBM directly
 
 struct CountParams {
@@ -53,47 +53,93 @@ __device__ __forceinline__ uint32_t word_index(uint64_t reg, const CountParams& 
     return idx;
 }
 
-// chunks per record + exclusive scan -> chunk_start[n+1].  One workgroup; lanes own slices.
-__global__ __launch_bounds__(1024) void chunk_scan_kernel(const uint64_t* __restrict__ offsets, uint32_t n,
-                                                          uint32_t* __restrict__ chunk_start) {
-    __shared__ uint32_t part[1024];
-    const uint32_t t = threadIdx.x;
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t lo = min(t * per, n), hi = min(lo + per, n);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint64_t len = offsets[i + 1] - offsets[i];
-        sum += (uint32_t)((len + kSpan - 1) / kSpan);
-    }
-    part[t] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {      // Hillis-Steele inclusive scan
-        uint32_t v = (t >= d) ? part[t - d] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[t] - sum;                  // exclusive prefix of this lane's slice
-    for (uint32_t i = lo; i < hi; ++i) {
-        chunk_start[i] = run;
-        const uint64_t len = offsets[i + 1] - offsets[i];
-        run += (uint32_t)((len + kSpan - 1) / kSpan);
-    }
-    if (t == 1023) chunk_start[n] = part[1023];
+__device__ __forceinline__ uint32_t chunks_of(const uint64_t* offsets, uint32_t i) {
+    return (uint32_t)((offsets[i + 1] - offsets[i] + kSpan - 1) / kSpan);
 }
 
+// ---- chunks per record, exclusive scan -> chunk_start[n+1]: three small launches ----------------
+// (1) per-1024-record block sums, (2) scan of the block sums, (3) local scan + block offset.
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const uint64_t* __restrict__ offsets, uint32_t n,
+                                                              uint32_t* __restrict__ blocksum) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t s = 0;
+    for (uint32_t e = 0; e < 4; ++e)
+        if (base + e < n) s += chunks_of(offsets, base + e);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ blocksum, uint32_t nb,
+                                                         uint32_t* __restrict__ total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {                    // 1024 block sums (1M records) per round
+        const uint32_t v = (b0 + t < nb) ? blocksum[b0 + t] : 0u;
+        part[t] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            const uint32_t u = (t >= d) ? part[t - d] : 0u;
+            __syncthreads();
+            part[t] += u;
+            __syncthreads();
+        }
+        if (b0 + t < nb) blocksum[b0 + t] = carry + part[t] - v;    // exclusive
+        const uint32_t round_total = part[1023];
+        __syncthreads();
+        carry += round_total;
+    }
+    if (t == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restrict__ offsets, uint32_t n,
+                                                         const uint32_t* __restrict__ blocksum,
+                                                         const uint32_t* __restrict__ total,
+                                                         uint32_t* __restrict__ chunk_start) {
+    __shared__ uint32_t part[256];
+    const uint32_t t = threadIdx.x;
+    const uint32_t base = blockIdx.x * 1024 + t * 4;
+    uint32_t c[4], s = 0;
+    for (uint32_t e = 0; e < 4; ++e) {
+        c[e] = (base + e < n) ? chunks_of(offsets, base + e) : 0u;
+        s += c[e];
+    }
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t u = (t >= d) ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += u;
+        __syncthreads();
+    }
+    uint32_t run = blocksum[blockIdx.x] + part[t] - s;
+    for (uint32_t e = 0; e < 4; ++e) {
+        if (base + e < n) chunk_start[base + e] = run;
+        run += c[e];
+    }
+    if (blockIdx.x == 0 && t == 0) chunk_start[n] = *total;
+}
+
+// ---- counting: one WAVE per chunk, no workgroup barrier -------------------------------------------
 template <bool LDS_HIST>
 __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restrict__ seq,
                                                          const uint64_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ chunk_start,
-                                                         CountParams P, uint32_t* __restrict__ counts,
+                                                         CountParams P, uint32_t waves_per_block,
+                                                         uint32_t* __restrict__ counts,
                                                          unsigned long long* __restrict__ totals) {
     extern __shared__ __align__(16) uint32_t smem[];
-    uint8_t* codes = reinterpret_cast<uint8_t*>(smem);            // [kStage]
-    uint32_t* hist = smem + kStage / 4;                            // [dim] when LDS_HIST
-    uint32_t* blk_total = hist + (LDS_HIST ? P.dim : 0);           // [1]
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= waves_per_block) return;
+    const uint32_t per_wave_words = kStage / 4 + (LDS_HIST ? P.dim : 0);
+    uint32_t* mine = smem + wave * per_wave_words;
+    uint8_t* codes = reinterpret_cast<uint8_t*>(mine);            // [kStage]
+    uint32_t* hist = mine + kStage / 4;                            // [dim] when LDS_HIST
 
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.x * waves_per_block + wave;
     const uint32_t nchunks = chunk_start[P.n_seqs];
     if (b >= nchunks) return;                                      // grid is an upper bound
     uint32_t lo = 0, hi = P.n_seqs;                                // last record with chunk_start <= b
@@ -111,13 +157,11 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     const uint64_t a0 = (off + (uint64_t)p_lo) & ~(uint64_t)15;    // 16 B aligned staging origin
     const int64_t pos0 = (int64_t)a0 - (int64_t)off;               // record position of staged byte 0
 
-    const uint32_t t = threadIdx.x;
     if (LDS_HIST)
-        for (uint32_t d = t; d < P.dim; d += kThreads) hist[d] = 0;
-    if (t == 0) *blk_total = 0;
+        for (uint32_t d = lane * 4; d < P.dim; d += 256) *reinterpret_cast<uint4*>(hist + d) = make_uint4(0, 0, 0, 0);
 
-    // ---- stage + decode -------------------------------------------------------------------
-    for (uint32_t v = t; v < kStage / 16; v += kThreads) {
+    // ---- stage + decode (aligned 16-byte loads, one decode per base) ---------------------------
+    for (uint32_t v = lane; v < kStage / 16; v += 64) {
         const uint64_t a = a0 + (uint64_t)v * 16;
         uint32_t w[4] = {0, 0, 0, 0};
         if (a + 16 <= P.total_bytes) {
@@ -142,19 +186,21 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
         }
         *reinterpret_cast<uint4*>(codes + v * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();                               // LDS is in order within a wave
 
-    // ---- slide ------------------------------------------------------------------------------
+    // ---- slide: lane owns starts [32 lane, 32 lane + 32) ---------------------------------------------
     const uint32_t W = P.window;
     const bool want_plus = P.strand != PO_STRAND_MINUS;
     const bool want_minus = P.strand != PO_STRAND_PLUS;
-    uint32_t mine = 0;
+    uint32_t mine_count = 0;
     {
-        const uint4 q0 = *reinterpret_cast<const uint4*>(codes + t * 16);
-        const uint4 q1 = *reinterpret_cast<const uint4*>(codes + t * 16 + 16);
-        const uint4 q2 = *reinterpret_cast<const uint4*>(codes + t * 16 + 32);
-        const uint32_t cw[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-        const int64_t first = pos0 + (int64_t)t * kPerLane;        // record position of this lane's start 0
+        uint32_t cw[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4*>(codes + lane * kPerLane + 16 * q);
+            cw[4 * q] = v.x; cw[4 * q + 1] = v.y; cw[4 * q + 2] = v.z; cw[4 * q + 3] = v.w;
+        }
+        const int64_t first = pos0 + (int64_t)lane * kPerLane;     // record position of this lane's start 0
         uint64_t fwd = 0, rev = 0;
         uint32_t run = 0;
         const uint32_t top = 2 * W - 2;
@@ -173,13 +219,13 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                             const uint32_t idx = word_index(fwd, P);
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
-                            ++mine;
+                            ++mine_count;
                         }
                         if (want_minus) {
                             const uint32_t idx = word_index(rev, P);
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
-                            ++mine;
+                            ++mine_count;
                         }
                     }
                 }
@@ -188,8 +234,8 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     }
 
     // ---- junction words of seq + revcomp(seq) (-s both), by the chunk holding the record end ----
-    if (P.strand == PO_STRAND_BOTH && chunk == rec_chunks - 1 && t < W - 1) {
-        const int64_t p = L - (int64_t)W + 1 + (int64_t)t;          // start in the 2L-long virtual string
+    if (P.strand == PO_STRAND_BOTH && chunk == rec_chunks - 1 && lane < W - 1) {
+        const int64_t p = L - (int64_t)W + 1 + (int64_t)lane;       // start in the 2L-long virtual string
         if (p >= 0 && p < L && p + (int64_t)W <= 2 * L) {
             uint32_t idx = 0;
             bool ok = true;
@@ -204,24 +250,27 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
             if (ok) {
                 if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                 else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
-                ++mine;
+                ++mine_count;
             }
         }
     }
 
-    // ---- totals: wave reduce, one LDS add per wave, one HBM add per chunk ------------------------
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
-    if ((t & 63u) == 0 && mine) atomicAdd(blk_total, mine);
-    __syncthreads();
-    if (t == 0 && *blk_total) atomicAdd(&totals[rec], (unsigned long long)*blk_total);
+    // ---- totals: wave reduce, one store / atomic per chunk ----------------------------------------
+    for (int o = 32; o > 0; o >>= 1) mine_count += __shfl_down(mine_count, o, 64);
+    if (lane == 0) {
+        if (rec_chunks == 1) totals[rec] = mine_count;
+        else if (mine_count) atomicAdd(&totals[rec], (unsigned long long)mine_count);
+    }
 
-    // ---- flush ------------------------------------------------------------------------------
+    // ---- flush ----------------------------------------------------------------------------------
     if (LDS_HIST) {
+        __builtin_amdgcn_wave_barrier();
         uint32_t* row = counts + (uint64_t)rec * P.dim;
         if (rec_chunks == 1) {
-            for (uint32_t d = t; d < P.dim; d += kThreads) row[d] = hist[d];
+            for (uint32_t d = lane * 4; d < P.dim; d += 256)
+                *reinterpret_cast<uint4*>(row + d) = *reinterpret_cast<const uint4*>(hist + d);
         } else {
-            for (uint32_t d = t; d < P.dim; d += kThreads) {
+            for (uint32_t d = lane; d < P.dim; d += 64) {
                 const uint32_t v = hist[d];
                 if (v) atomicAdd(&row[d], v);
             }
@@ -239,15 +288,24 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets
     const uint64_t max_chunks = total_bytes / kSpan + n_seqs;
     if (max_chunks >= (1ull << 31)) { po_set_error("input too large for one launch"); return PO_EUNSUPPORTED; }
 
-    int rc = po_buf_reserve(ctx, &ctx->ws_aux, (n_seqs + 1) * sizeof(uint32_t));
+    const uint32_t nb = (uint32_t)((n_seqs + 1023) / 1024);
+    int rc = po_buf_reserve(ctx, &ctx->ws_aux, (n_seqs + 1 + nb + 1) * sizeof(uint32_t));
     if (rc) return rc;
     uint32_t* chunk_start = static_cast<uint32_t*>(ctx->ws_aux.p);
+    uint32_t* blocksum = chunk_start + n_seqs + 1;
+    uint32_t* total = blocksum + nb;
 
+    // rows of single-chunk records are written whole by their wave; only multi-chunk records (rare:
+    // longer than 2 kb) accumulate with atomics and need zeros first.  Zero everything: 1 memset.
     PO_HIP(hipMemsetAsync(d_counts, 0, n_seqs * (uint64_t)pat.dim * sizeof(uint32_t), ctx->stream));
     PO_HIP(hipMemsetAsync(d_totals, 0, n_seqs * sizeof(uint64_t), ctx->stream));
 
-    hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_offsets, (uint32_t)n_seqs, chunk_start);
-    PO_CHECK_LAUNCH("chunk_scan_kernel");
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_offsets, (uint32_t)n_seqs, blocksum);
+    PO_CHECK_LAUNCH("scan_block_sums_kernel");
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, blocksum, nb, total);
+    PO_CHECK_LAUNCH("scan_sums_kernel");
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_offsets, (uint32_t)n_seqs, blocksum, total, chunk_start);
+    PO_CHECK_LAUNCH("scan_apply_kernel");
 
     CountParams P;
     memset(&P, 0, sizeof(P));
@@ -261,14 +319,18 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets
     P.total_bytes = total_bytes;
 
     const bool lds_hist = pat.dim <= kMaxLdsBins;
-    const size_t shmem = kStage + (lds_hist ? (size_t)pat.dim * 4 : 0) + 16;
+    const size_t per_wave = kStage + (lds_hist ? (size_t)pat.dim * 4 : 0);
+    uint32_t wpb = (uint32_t)((80u << 10) / per_wave);                // waves per workgroup within 80 KiB of LDS
+    wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
+    const size_t shmem = per_wave * wpb;
+    const uint32_t grid = (uint32_t)((max_chunks + wpb - 1) / wpb);
     unsigned long long* tot = reinterpret_cast<unsigned long long*>(d_totals);
     if (lds_hist) {
-        hipLaunchKernelGGL(count_kernel<true>, dim3((uint32_t)max_chunks), dim3(kThreads), shmem, ctx->stream,
-                           d_seq, d_offsets, chunk_start, P, d_counts, tot);
+        auto k = count_kernel<true>;
+        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), shmem, ctx->stream, d_seq, d_offsets, chunk_start, P, wpb, d_counts, tot);
     } else {
-        hipLaunchKernelGGL(count_kernel<false>, dim3((uint32_t)max_chunks), dim3(kThreads), shmem, ctx->stream,
-                           d_seq, d_offsets, chunk_start, P, d_counts, tot);
+        hipLaunchKernelGGL(count_kernel<false>, dim3(grid), dim3(kThreads), shmem, ctx->stream, d_seq, d_offsets, chunk_start, P, wpb, d_counts, tot);
     }
     PO_CHECK_LAUNCH("count_kernel");
     return PO_OK;
