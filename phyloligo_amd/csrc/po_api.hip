@@ -295,6 +295,10 @@ static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
         rc = po_buf_reserve(ctx, &ctx->ws_aux, po_gram_i8_workspace(n, dim));
         if (rc) return rc;
     }
+    if (metric == PO_BC) {
+        rc = po_buf_reserve(ctx, &ctx->ws_aux, po_bc_sad_workspace(n, dim));
+        if (rc) return rc;
+    }
     return PO_OK;
 }
 
@@ -382,6 +386,11 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         rc = po_launch_jsd_lut_prep(ctx, d_counts, d_totals, n, dim, npad, ctx->ws_aux.p, &cls);
         if (rc) return rc;
     }
+    if (metric == PO_BC && d_counts && !(flags & PO_FLAG_NO_TABLE_PATH)) {
+        // same split for Bray-Curtis: equal-total record blocks with byte-sized counts take the packed SAD kernel
+        rc = po_launch_bc_sad_prep(ctx, d_counts, d_totals, n, dim, npad, ctx->ws_aux.p, &cls);
+        if (rc) return rc;
+    }
     if (stats) PO_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
 
     // ---- tiles, block by block ----
@@ -415,7 +424,14 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
                 rc = po_launch_valu_tiles(ctx, PO_JSD, a, cls, cls ? nullptr : &tiles);
                 kid = cls ? PO_KERNEL_LUT_JSD : PO_KERNEL_VALU_JSD;
                 break;
-            case PO_BC: rc = po_launch_valu_tiles(ctx, PO_BC, a, nullptr, &tiles); kid = PO_KERNEL_VALU_BC; break;
+            case PO_BC:
+                if (cls) {
+                    rc = po_launch_bc_sad_tiles(ctx, a, ctx->ws_aux.p, &tiles);
+                    if (rc) return rc;
+                }
+                rc = po_launch_valu_tiles(ctx, PO_BC, a, cls, cls ? nullptr : &tiles);
+                kid = cls ? PO_KERNEL_SAD_BC : PO_KERNEL_VALU_BC;
+                break;
             case PO_EUCL:
                 if (i8flag) {
                     rc = po_launch_gram_i8_tiles(ctx, a, ctx->ws_aux.p, &tiles);

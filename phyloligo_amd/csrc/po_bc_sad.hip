@@ -1,0 +1,194 @@
+// Stage 2, Bray-Curtis fast path for record pairs with EQUAL word totals: packed-byte SAD.
+//
+// Same quantity as valu_tile_kernel<BC> ('braycurtis' at
+// /root/reference/phylopackage/bin/phyloligo.py:381 -> SciPy: sum|a-b| / sum|a+b|).  When two records have
+// the same number of counted words n, |a_w - b_w| = |ca_w - cb_w| / n, so the numerator is an exact integer
+// sum of absolute count differences.  With counts <= 255 four words fit one register and
+// v_sad_u8 (sum of absolute differences of 4 byte pairs + accumulate) does four words per instruction:
+// the per-pair cost drops from 2 float64 instructions per word to 1/4 integer instruction per word.
+//
+// Eligibility is per tile, decided on the device exactly as for the JSD table kernel: classify marks every
+// block of 128 records with its common total (0 = mixed, empty, or a count above 255); a tile takes this
+// path iff both classes are equal and non-zero, every other tile is left to valu_tile_kernel<BC>.
+#include "po_tiles.h"
+
+namespace {
+
+constexpr int TM = 128, TN = 128;
+constexpr int KC = 8;                                  // packed word groups (4 words each) per staging step
+constexpr int kThreads = 256;
+constexpr int kStageWords = KC * (TM + TN);            // uint32 per buffer
+
+// P8t[g][npad] = bytes (c[4g], c[4g+1], c[4g+2], c[4g+3]) of record n, clamped to 255, zero padded
+__global__ __launch_bounds__(256) void prep_pack8_kernel(const uint32_t* __restrict__ counts, uint64_t n, uint32_t dim,
+                                                         uint32_t groups_pad, uint64_t npad, uint32_t* __restrict__ p8t,
+                                                         uint32_t* __restrict__ maxcount) {
+    __shared__ uint32_t tile[64][65];
+    const uint64_t n0 = (uint64_t)blockIdx.x * 64;
+    const uint32_t g0 = blockIdx.y * 64;
+    const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    uint32_t mx = 0;
+    for (uint32_t r = ty; r < 64; r += 4) {                        // r: record, tx: group
+        const uint64_t row = n0 + r;
+        uint32_t packed = 0;
+        const uint32_t d = (g0 + tx) * 4;
+        if (row < n) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t v = (d + e < dim) ? counts[row * dim + d + e] : 0u;
+                mx = max(mx, v);
+                packed |= min(v, 255u) << (8 * e);
+            }
+        }
+        tile[r][tx] = packed;
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > *maxcount) atomicMax(maxcount, mx);
+    __syncthreads();
+    for (uint32_t r = ty; r < 64; r += 4)                          // r: group, tx: record
+        if (g0 + r < groups_pad && n0 + tx < npad) p8t[(uint64_t)(g0 + r) * npad + n0 + tx] = tile[tx][r];
+}
+
+__global__ __launch_bounds__(128) void classify_bc_kernel(const unsigned long long* __restrict__ totals, uint64_t n,
+                                                          const uint32_t* __restrict__ maxcount,
+                                                          unsigned long long* __restrict__ cls) {
+    const uint64_t r = (uint64_t)blockIdx.x * 128 + threadIdx.x;
+    const unsigned long long ref = totals[(uint64_t)blockIdx.x * 128];
+    const bool ok = (r >= n) || (totals[r] == ref);
+    const int all = __syncthreads_and(ok ? 1 : 0);
+    if (threadIdx.x == 0) cls[blockIdx.x] = (all && ref > 0 && *maxcount <= 255u) ? ref : 0ull;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef const __attribute__((address_space(1))) unsigned char glb_byte;
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((glb_byte*)gptr, (lds_byte*)lds_base, 16, 0, 0);
+}
+#else
+__device__ __forceinline__ void glds16(const void*, void*) {}
+#endif
+
+template <typename OUT>
+__global__ __launch_bounds__(kThreads, 2) void bc_sad_tile_kernel(po_tile_args A, const uint32_t* __restrict__ p8t,
+                                                                  uint32_t groups_pad,
+                                                                  const unsigned long long* __restrict__ cls) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem);          // [2][A: KC x 128 | B: KC x 128]
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t tx = t & 15, ty = t >> 4;
+    const uint32_t lane = t & 63, wave = t >> 6;
+
+    uint32_t ti, tj;
+    po_tile_coords(A, TM, blockIdx.x, ti, tj);
+    const unsigned long long ntot = cls[ti];
+    if (ntot == 0 || cls[tj] != ntot) return;                      // valu_tile_kernel<BC> owns this tile
+    const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
+
+    uint32_t acc[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = 0u;
+
+    auto gstage = [&](uint32_t g0, uint32_t buf) {                  // wave w: groups 2w, 2w+1 of A and of B
+        const uint32_t g = wave * 2 + (lane >> 5);
+        const uint32_t* row = p8t + (uint64_t)(g0 + g) * A.npad + (lane & 31) * 4;
+        uint32_t* dst = stage + buf * kStageWords + wave * 2 * TM;
+        glds16(row + i0, dst);
+        glds16(row + j0, dst + KC * TM);
+    };
+    gstage(0, 0);
+    __syncthreads();
+
+    uint32_t cur = 0;
+    for (uint32_t g0 = 0; g0 < groups_pad; g0 += KC) {
+        if (g0 + KC < groups_pad) gstage(g0 + KC, cur ^ 1);
+        const uint32_t* sA = stage + cur * kStageWords + ty * 8;
+        const uint32_t* sB = stage + cur * kStageWords + KC * TM + tx * 2;
+#pragma unroll 4
+        for (int k = 0; k < KC; ++k) {
+            const uint4 a0 = *reinterpret_cast<const uint4*>(sA + k * TM);
+            const uint4 a1 = *reinterpret_cast<const uint4*>(sA + k * TM + 4);
+            const uint32_t a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            uint32_t b[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint2 bv = *reinterpret_cast<const uint2*>(sB + k * TN + 32 * q);
+                b[2 * q] = bv.x; b[2 * q + 1] = bv.y;
+            }
+#pragma unroll
+            for (int ia = 0; ia < 8; ++ia)
+#pragma unroll
+                for (int ib = 0; ib < 8; ++ib) acc[ia][ib] = __builtin_amdgcn_sad_u8(a[ia], b[ib], acc[ia][ib]);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: BC = (num / n) / (w_i + w_j) ------------------------------------------------------
+    const double inv_n = 1.0 / (double)ntot;
+    const double* st1 = A.rowstat + A.npad;        // sum f of each record
+    double wi[8];
+#pragma unroll
+    for (int ia = 0; ia < 8; ++ia) wi[ia] = st1[i0 + ty * 8 + ia];
+    double v[8][8];
+#pragma unroll
+    for (int ib = 0; ib < 8; ++ib) {
+        const uint64_t j = min(j0 + 32 * (ib >> 1) + 2 * tx + (ib & 1), A.npad - 1);
+        const double wj = st1[j];
+#pragma unroll
+        for (int ia = 0; ia < 8; ++ia) {
+            const uint64_t i = i0 + ty * 8 + ia;
+            v[ia][ib] = (i == j) ? 0.0 : ((double)acc[ia][ib] * inv_n) / (wi[ia] + wj);
+        }
+    }
+    po_store_block<OUT, 8, kThreads>(A, ti, tj, i0, j0, tx, ty, v, reinterpret_cast<double*>(smem));
+}
+
+}  // namespace
+
+static inline uint32_t bc_groups_pad(uint32_t dim) { return (uint32_t)po_round_up((dim + 3) / 4, KC); }
+
+size_t po_bc_sad_workspace(uint64_t n, uint32_t dim) {
+    const uint64_t npad = po_round_up(n ? n : 1, 128);
+    return (size_t)bc_groups_pad(dim) * npad * sizeof(uint32_t) + npad / 128 * sizeof(unsigned long long) + 256;
+}
+
+// ws layout: packed matrix | classes | maxcount
+int po_launch_bc_sad_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                          uint64_t npad, void* ws, const unsigned long long** cls_out) {
+    const uint32_t gp = bc_groups_pad(dim);
+    uint8_t* base = static_cast<uint8_t*>(ws);
+    uint32_t* p8t = reinterpret_cast<uint32_t*>(base);
+    unsigned long long* cls = reinterpret_cast<unsigned long long*>(base + (size_t)gp * npad * sizeof(uint32_t));
+    uint32_t* maxcount = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(cls) + npad / 128 * sizeof(unsigned long long));
+    PO_HIP(hipMemsetAsync(maxcount, 0, sizeof(uint32_t), ctx->stream));
+    dim3 grid((uint32_t)(npad / 64), (gp + 63) / 64);
+    hipLaunchKernelGGL(prep_pack8_kernel, grid, dim3(256), 0, ctx->stream, d_counts, n, dim, gp, npad, p8t, maxcount);
+    PO_CHECK_LAUNCH("prep_pack8_kernel");
+    hipLaunchKernelGGL(classify_bc_kernel, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, ctx->stream,
+                       reinterpret_cast<const unsigned long long*>(d_totals), n, maxcount, cls);
+    PO_CHECK_LAUNCH("classify_bc_kernel");
+    *cls_out = cls;
+    return PO_OK;
+}
+
+int po_launch_bc_sad_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint64_t* tiles) {
+    const uint32_t gp = bc_groups_pad(a.dim);
+    const uint8_t* base = static_cast<const uint8_t*>(ws);
+    const uint32_t* p8t = reinterpret_cast<const uint32_t*>(base);
+    const unsigned long long* cls = reinterpret_cast<const unsigned long long*>(base + (size_t)gp * a.npad * sizeof(uint32_t));
+    const uint64_t nblocks = po_tile_count(a, TM);
+    if (tiles) *tiles += nblocks;
+    if (nblocks == 0) return PO_OK;
+    if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
+    const size_t shmem = kMirrorLdsBytes > 2 * kStageWords * sizeof(uint32_t) ? (size_t)kMirrorLdsBytes : 2 * kStageWords * sizeof(uint32_t);
+    if (a.out_f32)
+        hipLaunchKernelGGL(bc_sad_tile_kernel<float>, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, p8t, gp, cls);
+    else
+        hipLaunchKernelGGL(bc_sad_tile_kernel<double>, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, p8t, gp, cls);
+    PO_CHECK_LAUNCH("bc_sad_tile_kernel");
+    return PO_OK;
+}

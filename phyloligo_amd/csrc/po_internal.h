@@ -116,6 +116,10 @@ size_t po_jsd_lut_workspace(uint64_t n, uint32_t dim);
 int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
                            uint64_t npad, void* ws, const unsigned long long** cls_out);
 int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, const void* ws, uint64_t* tiles);
+size_t po_bc_sad_workspace(uint64_t n, uint32_t dim);
+int po_launch_bc_sad_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                          uint64_t npad, void* ws, const unsigned long long** cls_out);
+int po_launch_bc_sad_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint64_t* tiles);
 size_t po_gram_i8_workspace(uint64_t n, uint32_t dim);
 int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
                            uint64_t npad, void* ws, const uint32_t** flag_out);

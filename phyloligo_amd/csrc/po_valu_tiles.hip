@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kThreads, 2) void valu_tile_kernel(po_tile_args A, 
 
     uint32_t ti, tj;
     po_tile_coords(A, TM, blockIdx.x, ti, tj);
-    if (METRIC == PO_JSD && cls != nullptr) {          // tiles of equal-total record blocks belong to po_jsd_lut.hip
+    if (cls != nullptr) {      // tiles of equal-total record blocks belong to po_jsd_lut.hip / po_bc_sad.hip
         const unsigned long long c = cls[ti];
         if (c != 0 && cls[tj] == c) return;
     }
@@ -384,7 +384,7 @@ int po_launch_valu_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const u
         if (variant == 1) return launch_metric<PO_JSD, 1>(ctx, a, cls, tiles);
         return launch_metric<PO_JSD, 0>(ctx, a, cls, tiles);
     }
-    if (metric == PO_BC) return launch_metric<PO_BC, 0>(ctx, a, nullptr, tiles);
+    if (metric == PO_BC) return launch_metric<PO_BC, 0>(ctx, a, cls, tiles);
     po_set_error("po_launch_valu_tiles: metric %d is not an elementwise-reduction metric", metric);
     return PO_EINVAL;
 }

@@ -244,3 +244,27 @@ def test_eucl_int8_and_float64_mfma_paths(ctx):
     assert got[7, len(small) - 1] == 0.0                     # duplicate records: exactly 0, like (a-b)^2
     got32 = ctx.pairwise(counts, totals, "Eucl", dtype="float32")
     np.testing.assert_array_equal(got32, got.astype(np.float32))
+
+
+@pytest.mark.parametrize("pattern", ["1111", "11011011"])
+def test_bc_equal_total_sad_path_and_mixed_tiles(ctx, pattern):
+    """Equal-total record blocks take the packed-byte SAD kernel, the others the float64 kernel."""
+    from oracle import phyloligo_oracle as po
+    rng = np.random.default_rng(31)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    fixed = [alpha[rng.integers(0, 4, size=1200)].tobytes() for _ in range(300)]
+    ragged = _random_assembly(150, 32, lo=400, hi=2000)
+    contigs = fixed[:256] + ragged[:70] + fixed[256:] + ragged[70:] + [b"", b""]
+    seq, offsets = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, offsets, pattern, "both")
+    oc, ot = po.compute_counts(contigs, pattern, "both")
+    want = po.pairwise_block(po.counts_to_frequencies(oc, ot), "BC")
+    got, st = ctx.pairwise(counts, totals, "BC", want_stats=True)
+    assert st["kernel_id"] == 7
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL, equal_nan=True)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    gen, st2 = ctx.pairwise(counts, totals, "BC", want_stats=True, table_path=False)
+    assert st2["kernel_id"] == 2
+    np.testing.assert_allclose(gen, want, rtol=RTOL, atol=ATOL, equal_nan=True)
+    np.testing.assert_allclose(ctx.pairwise(counts, totals, "BC", row_begin=130, row_end=390), want[130:390],
+                               rtol=RTOL, atol=ATOL, equal_nan=True)

@@ -24,7 +24,7 @@ for name, n, pat, metric, seed in configs:
         if best is None or st['total_ms'] < best['total_ms']: best = st
     pairs = n * (n - 1) / 2
     gen = ""
-    if metric in ("JSD", "Eucl"):
+    if metric in ("JSD", "Eucl", "BC"):
         _, st2 = ctx.pairwise(counts, totals, metric, out=out, want_stats=True, table_path=False)
         _, st2 = ctx.pairwise(counts, totals, metric, out=out, want_stats=True, table_path=False)
         gen = " | general kernel only: %.2f ms %.3e pairs/s" % (st2['total_ms'], pairs / (st2['total_ms'] * 1e-3))
