@@ -59,15 +59,6 @@ __global__ __launch_bounds__(128) void classify_bc_kernel(const unsigned long lo
     if (threadIdx.x == 0) cls[blockIdx.x] = (all && ref > 0 && *maxcount <= 255u) ? ref : 0ull;
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef __attribute__((address_space(3))) unsigned char lds_byte;
-typedef const __attribute__((address_space(1))) unsigned char glb_byte;
-__device__ __forceinline__ void glds16(const void* gptr, void* lds_base) {
-    __builtin_amdgcn_global_load_lds((glb_byte*)gptr, (lds_byte*)lds_base, 16, 0, 0);
-}
-#else
-__device__ __forceinline__ void glds16(const void*, void*) {}
-#endif
 
 template <typename OUT>
 __global__ __launch_bounds__(kThreads, 2) void bc_sad_tile_kernel(po_tile_args A, const uint32_t* __restrict__ p8t,
@@ -96,8 +87,8 @@ __global__ __launch_bounds__(kThreads, 2) void bc_sad_tile_kernel(po_tile_args A
         const uint32_t g = wave * 2 + (lane >> 5);
         const uint32_t* row = p8t + (uint64_t)(g0 + g) * A.npad + (lane & 31) * 4;
         uint32_t* dst = stage + buf * kStageWords + wave * 2 * TM;
-        glds16(row + i0, dst);
-        glds16(row + j0, dst + KC * TM);
+        po_glds16(row + i0, dst);
+        po_glds16(row + j0, dst + KC * TM);
     };
     gstage(0, 0);
     __syncthreads();

@@ -72,21 +72,6 @@ __global__ void lut_table_kernel(double* __restrict__ lut) {
 }
 
 
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef __attribute__((address_space(3))) unsigned char lds_byte;
-typedef const __attribute__((address_space(1))) unsigned char glb_byte;
-__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)((const lds_byte*)p); }
-__device__ __forceinline__ double lds_read_f64(uint32_t addr) {
-    return *((const __attribute__((address_space(3))) double*)(uintptr_t)addr);
-}
-__device__ __forceinline__ void glds16(const void* gptr, void* lds_base) {
-    __builtin_amdgcn_global_load_lds((glb_byte*)gptr, (lds_byte*)lds_base, 16, 0, 0);
-}
-#else
-__device__ __forceinline__ uint32_t lds_addr(const void*) { return 0; }
-__device__ __forceinline__ double lds_read_f64(uint32_t) { return 0.0; }
-__device__ __forceinline__ void glds16(const void*, void*) {}
-#endif
 
 // RPT rows per lane: 8 -> 256 lanes per 128 x 128 tile, 4 -> 512 lanes (more waves per SIMD to hide the
 // LDS round trips; the table is shared by twice as many waves).
@@ -126,18 +111,18 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void jsd_lut_tile_ker
         const uint32_t* row = ct + (uint64_t)(k0 + k) * A.npad + (lane & 31) * 4;
         uint32_t* dst = stage + buf * kStageWords + w4 * 2 * TM;
         if (RPT == 8) {
-            glds16(row + i0, dst);
-            glds16(row + j0, dst + KC * TM);
+            po_glds16(row + i0, dst);
+            po_glds16(row + j0, dst + KC * TM);
         } else if (wave < 4) {
-            glds16(row + i0, dst);
+            po_glds16(row + i0, dst);
         } else {
-            glds16(row + j0, dst + KC * TM);
+            po_glds16(row + j0, dst + KC * TM);
         }
     };
     gstage(0, 0);
     __syncthreads();
 
-    const uint32_t tcopy = lds_addr(tab) + (lane & 31) * 8;
+    const uint32_t tcopy = po_lds_addr(tab) + (lane & 31) * 8;
     uint32_t cur = 0;
     for (uint32_t k0 = 0; k0 < A.dim; k0 += KC) {
         if (k0 + KC < A.dim) gstage(k0 + KC, cur ^ 1);
@@ -160,12 +145,12 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void jsd_lut_tile_ker
             // the 8 lookups of register-block row ia+1 are in flight while row ia is accumulated
             double tv[2][8];
 #pragma unroll
-            for (int ib = 0; ib < 8; ++ib) tv[0][ib] = lds_read_f64(a[0] + b[ib]);
+            for (int ib = 0; ib < 8; ++ib) tv[0][ib] = po_lds_read_f64(a[0] + b[ib]);
 #pragma unroll
             for (int ia = 0; ia < RPT; ++ia) {
                 if (ia + 1 < RPT) {
 #pragma unroll
-                    for (int ib = 0; ib < 8; ++ib) tv[(ia + 1) & 1][ib] = lds_read_f64(a[ia + 1] + b[ib]);
+                    for (int ib = 0; ib < 8; ++ib) tv[(ia + 1) & 1][ib] = po_lds_read_f64(a[ia + 1] + b[ib]);
                 }
 #pragma unroll
                 for (int ib = 0; ib < 8; ++ib) acc[ia][ib] += tv[ia & 1][ib];

@@ -14,6 +14,29 @@ static inline uint64_t po_tile_count(const po_tile_args& a, uint32_t edge) {
 }
 
 #if defined(__HIPCC__)
+// ---- LDS helpers -----------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) unsigned char po_lds_byte;
+typedef const __attribute__((address_space(1))) unsigned char po_glb_byte;
+// raw LDS byte address of a __shared__ pointer
+__device__ __forceinline__ uint32_t po_lds_addr(const void* p) { return (uint32_t)(uintptr_t)((const po_lds_byte*)p); }
+__device__ __forceinline__ double2 po_lds_read_d2(uint32_t addr) {
+    return *((const __attribute__((address_space(3))) double2*)(uintptr_t)addr);
+}
+__device__ __forceinline__ double po_lds_read_f64(uint32_t addr) {
+    return *((const __attribute__((address_space(3))) double*)(uintptr_t)addr);
+}
+// LDS-DMA: 64 lanes x 16 B straight from global memory into 1 KiB of LDS at `lds_base` (wave uniform)
+__device__ __forceinline__ void po_glds16(const void* gptr, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((po_glb_byte*)gptr, (po_lds_byte*)lds_base, 16, 0, 0);
+}
+#else
+__device__ __forceinline__ uint32_t po_lds_addr(const void*) { return 0; }
+__device__ __forceinline__ double2 po_lds_read_d2(uint32_t) { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ double po_lds_read_f64(uint32_t) { return 0.0; }
+__device__ __forceinline__ void po_glds16(const void*, void*) {}
+#endif
+
 // linear id -> tile of the upper triangle of a T x T tile grid (tj >= ti), row major
 __device__ __forceinline__ void po_tri_decode(uint64_t b, uint32_t T, uint32_t& ti, uint32_t& tj) {
     const double tt = 2.0 * T + 1.0;
