@@ -10,6 +10,13 @@
 // .mat: numpy.savetxt(path, m, delimiter="\t") (/root/reference/phylopackage/bin/phyloligo.py:1061,
 // :1066) = "%.18e" per value, '\t' between columns, '\n' after every row, nothing else.
 #include <errno.h>
+
+#include <algorithm>
+#include <charconv>
+#include <functional>
+#include <thread>
+#include <vector>
+
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -83,6 +90,34 @@ extern "C" int po_fasta_extract(const uint8_t* data, uint64_t len, uint8_t* seq_
     return fasta_walk(data, len, seq_out ? seq_out : &dummy, offsets_out, title_begin, title_end, nullptr, nullptr);
 }
 
+// "%.18e" of one value into p, numpy spelling of non-finite values; returns the new end.
+static inline char* format_e18(char* p, double v) {
+    if (isnan(v)) { memcpy(p, "nan", 3); return p + 3; }
+    if (isinf(v)) {
+        if (v < 0) { memcpy(p, "-inf", 4); return p + 4; }
+        memcpy(p, "inf", 3);
+        return p + 3;
+    }
+    // std::to_chars(scientific, 18) prints exactly what printf("%.18e") prints (correctly rounded digits,
+    // at least two exponent digits) at a fraction of the cost
+    auto r = std::to_chars(p, p + 32, v, std::chars_format::scientific, 18);
+    return r.ptr;
+}
+
+// Formats rows [r0, r1) into `out` (cleared first).
+static void format_rows(const double* m, uint64_t r0, uint64_t r1, uint64_t cols, uint64_t ld, std::vector<char>& out) {
+    out.clear();
+    out.reserve((size_t)((r1 - r0) * cols * 26 + 16));
+    for (uint64_t r = r0; r < r1; ++r) {
+        for (uint64_t c = 0; c < cols; ++c) {
+            char tmp[40];
+            char* e = format_e18(tmp, m[r * ld + c]);
+            *e++ = (c + 1 == cols) ? '\n' : '\t';
+            out.insert(out.end(), tmp, e);
+        }
+    }
+}
+
 extern "C" int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, uint64_t ld, const char* path,
                                  int append) {
     if (!path || (!m && rows && cols) || ld < cols) {
@@ -94,38 +129,29 @@ extern "C" int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, 
         po_set_error("cannot open %s: %s", path, strerror(errno));
         return PO_EIO;
     }
-    const size_t cap = 1u << 20;
-    char* buf = static_cast<char*>(malloc(cap + 64));
-    if (!buf) {
-        fclose(fh);
-        po_set_error("po_write_mat_text: out of memory");
-        return PO_ENOMEM;
-    }
-    size_t used = 0;
     int rc = PO_OK;
-    for (uint64_t r = 0; r < rows && rc == PO_OK; ++r) {
-        for (uint64_t c = 0; c < cols; ++c) {
-            const double v = m[r * ld + c];
-            if (isnan(v)) {
-                memcpy(buf + used, "nan", 3);
-                used += 3;
-            } else if (isinf(v)) {
-                const char* s = v < 0 ? "-inf" : "inf";
-                const size_t l = strlen(s);
-                memcpy(buf + used, s, l);
-                used += l;
-            } else {
-                used += (size_t)snprintf(buf + used, 40, "%.18e", v);
+    if (rows && cols) {
+        // rows are formatted by a pool of host threads, a slab of rows each, and written in order
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned nthreads = (rows * cols < (1u << 16)) ? 1u : (hw == 0 ? 4u : (hw > 32u ? 32u : hw));
+        const uint64_t slab = std::max<uint64_t>(1, std::min<uint64_t>((rows + nthreads - 1) / nthreads, (4u << 20) / (cols * 25 + 1) + 1));
+        std::vector<std::vector<char>> bufs(nthreads);
+        for (uint64_t base = 0; base < rows && rc == PO_OK; base += slab * nthreads) {
+            std::vector<std::thread> pool;
+            unsigned used = 0;
+            for (unsigned t = 0; t < nthreads; ++t) {
+                const uint64_t r0 = base + t * slab;
+                if (r0 >= rows) break;
+                const uint64_t r1 = std::min(rows, r0 + slab);
+                ++used;
+                if (nthreads == 1) format_rows(m, r0, r1, cols, ld, bufs[t]);
+                else pool.emplace_back(format_rows, m, r0, r1, cols, ld, std::ref(bufs[t]));
             }
-            buf[used++] = (c + 1 == cols) ? '\n' : '\t';
-            if (used >= cap) {
-                if (fwrite(buf, 1, used, fh) != used) { rc = PO_EIO; break; }
-                used = 0;
-            }
+            for (auto& th : pool) th.join();
+            for (unsigned t = 0; t < used; ++t)
+                if (fwrite(bufs[t].data(), 1, bufs[t].size(), fh) != bufs[t].size()) { rc = PO_EIO; break; }
         }
     }
-    if (rc == PO_OK && used && fwrite(buf, 1, used, fh) != used) rc = PO_EIO;
-    free(buf);
     if (fclose(fh) != 0) rc = PO_EIO;
     if (rc != PO_OK) po_set_error("write to %s failed: %s", path, strerror(errno));
     return rc;
