@@ -368,7 +368,7 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         if (rc) return rc;
     }
     if (metric == PO_JSD || metric == PO_BC) {
-        rc = po_launch_rowstat(ctx, ft, n, dim, npad, rowstat);
+        rc = po_launch_rowstat(ctx, ft, n, dim, npad, rowstat, metric == PO_JSD ? ctx->ws_logtab.p : nullptr);
     } else if (metric == PO_SC) {
         rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, ft, nullptr, rowstat);
     } else if (metric == PO_KT) {

@@ -92,7 +92,9 @@ int po_launch_prep_freq(po_ctx* ctx, const double* d_freq, uint64_t n, uint32_t 
 int po_launch_freq_rowmajor(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
                             uint32_t dim, double* d_freq);
 // rowstat[0][n] = sum f ln f, rowstat[1][n] = sum f
-int po_launch_rowstat(po_ctx* ctx, const double* d_ft, uint64_t n, uint32_t dim, uint64_t npad, double* d_rowstat);
+// logtab (may be NULL): the JSD log table; when given, rowstat[2] = sum f ln f by the tile kernel's table log
+int po_launch_rowstat(po_ctx* ctx, const double* d_ft, uint64_t n, uint32_t dim, uint64_t npad, double* d_rowstat,
+                      const void* logtab);
 
 // One rectangular block of the matrix handed to a tile kernel.
 struct po_tile_args {

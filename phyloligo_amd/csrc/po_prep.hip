@@ -59,23 +59,42 @@ __global__ __launch_bounds__(256) void freq_rowmajor_kernel(const uint32_t* __re
     }
 }
 
-// rowstat[0][r] = sum_w f ln f   (f > 0 terms), rowstat[1][r] = sum_w f (1 up to rounding, 0 for an empty record)
-// One lane per record, coalesced along n thanks to the transposed layout; the summation order
-// (w ascending) is fixed, so the value is reproducible.
+// rowstat[0][r] = sum_w f ln f (f > 0 terms, library log), rowstat[1][r] = sum_w f (1 up to rounding, 0 for
+// an empty record), rowstat[2][r] = sum_w f ln f again but with the SAME table logarithm, instruction for
+// instruction, that valu_tile_kernel<JSD> applies to a+b: its (tiny, systematic) errors then cancel in
+// 1/2 (E_a + E_b - S), and two identical records come out at rounding level instead of ~1e-13.
+// One lane per record, coalesced along n thanks to the transposed layout; fixed summation order.
 __global__ __launch_bounds__(256) void rowstat_kernel(const double* __restrict__ ft, uint64_t n, uint32_t dim,
-                                                      uint64_t npad, double* __restrict__ rowstat) {
+                                                      uint64_t npad, double* __restrict__ rowstat,
+                                                      const double2* __restrict__ logtab) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= npad) return;
-    double e = 0.0, s = 0.0;
+    const double LN2 = 0.693147180559945309417232121458;
+    double e = 0.0, s = 0.0, et = 0.0;
     if (r < n) {
         for (uint32_t d = 0; d < dim; ++d) {
             const double f = ft[(uint64_t)d * npad + r];
-            if (f > 0.0) e += f * log(f);
+            if (f > 0.0) {
+                e += f * log(f);
+                if (logtab != nullptr) {
+                    const uint32_t hi = (uint32_t)__double2hiint(f);
+                    const double2 te = logtab[((hi >> 13) & 127u) * 16];        // copy 0 of the interval's entry
+                    const double m = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(f));
+                    const double ef = (double)((hi >> 20) & 0x7FFu);
+                    const double rr = fma(m, te.x, -1.0);
+                    double q = fma(rr, -0.25, 1.0 / 3.0);
+                    q = fma(rr, q, -0.5);
+                    q = fma(rr, q, 1.0);
+                    const double big = fma(ef, LN2, te.y);
+                    et = fma(f, fma(rr, q, big), et);
+                }
+            }
             s += f;
         }
     }
     rowstat[r] = e;
     rowstat[npad + r] = s;
+    if (logtab != nullptr) rowstat[2 * npad + r] = et;
 }
 
 }  // namespace
@@ -107,9 +126,10 @@ int po_launch_freq_rowmajor(po_ctx* ctx, const uint32_t* d_counts, const uint64_
     return PO_OK;
 }
 
-int po_launch_rowstat(po_ctx* ctx, const double* d_ft, uint64_t n, uint32_t dim, uint64_t npad, double* d_rowstat) {
+int po_launch_rowstat(po_ctx* ctx, const double* d_ft, uint64_t n, uint32_t dim, uint64_t npad, double* d_rowstat,
+                      const void* logtab) {
     hipLaunchKernelGGL(rowstat_kernel, dim3((uint32_t)((npad + 255) / 256)), dim3(256), 0, ctx->stream, d_ft, n, dim,
-                       npad, d_rowstat);
+                       npad, d_rowstat, static_cast<const double2*>(logtab));
     PO_CHECK_LAUNCH("rowstat_kernel");
     return PO_OK;
 }

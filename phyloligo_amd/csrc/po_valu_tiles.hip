@@ -190,7 +190,8 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void valu_tile_kernel
     }
 
     // ---- epilogue -------------------------------------------------------------------------------
-    const double* st0 = A.rowstat;             // sum f ln f
+    // sum f ln f: for JSD the variant computed with this kernel's own table logarithm (errors cancel)
+    const double* st0 = A.rowstat + (METRIC == PO_JSD ? 2 * A.npad : 0);
     const double* st1 = A.rowstat + A.npad;    // sum f
     double ei[RPT], wi[RPT];
 #pragma unroll

@@ -268,3 +268,28 @@ def test_bc_equal_total_sad_path_and_mixed_tiles(ctx, pattern):
     np.testing.assert_allclose(gen, want, rtol=RTOL, atol=ATOL, equal_nan=True)
     np.testing.assert_allclose(ctx.pairwise(counts, totals, "BC", row_begin=130, row_end=390), want[130:390],
                                rtol=RTOL, atol=ATOL, equal_nan=True)
+
+
+def test_jsd_general_kernel_near_duplicates(ctx):
+    """Records that differ by one base, with different totals (general kernel): tiny JSD values keep their
+    relative accuracy, and exact duplicates come out at rounding level."""
+    from oracle import phyloligo_oracle as po
+    rng = np.random.default_rng(41)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    base = alpha[rng.integers(0, 4, size=3000)].copy()
+    contigs = []
+    for i in range(40):
+        s = base[:2000 + 13 * i].copy()
+        if i % 3 == 1:
+            s[500 + i] = alpha[(np.searchsorted(alpha, s[500 + i]) + 1) % 4]     # one substitution
+        contigs.append(s.tobytes())
+    contigs += [contigs[5], contigs[17]]                                           # exact duplicates
+    seq, offsets = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, offsets, "1111", "both")
+    oc, ot = po.compute_counts(contigs, "1111", "both")
+    want = po.pairwise_block(po.counts_to_frequencies(oc, ot), "JSD")
+    got, st = ctx.pairwise(counts, totals, "JSD", want_stats=True)
+    off = ~np.eye(len(contigs), dtype=bool)
+    assert want[off & (want > 0)].min() < 1e-4                                     # the regime this test is about
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-14)
+    assert abs(got[5, 40]) < 5e-14 and abs(got[17, 41]) < 5e-14      # accumulated rounding only
