@@ -19,7 +19,8 @@ namespace {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 constexpr int TM = 128, TN = 128;
-constexpr int KC = 8;
+constexpr int KC = 16;                            // words staged per step: 4 MFMA k-steps (4096 MFMA cycles) cover the
+                                                  // global-load latency of the next step's staging
 constexpr int kThreads = 256;
 constexpr int kRowStride = TM + TN + 16;          // +16 doubles: k-rows of one MFMA operand land in
 constexpr int kStageDoubles = KC * kRowStride;    // different bank halves (ds_read_b64, 32-lane groups)
@@ -70,29 +71,37 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
+    // staging through registers: lane loads 4 consecutive records of words (k0 + sk) and (k0 + sk + 8)
+    // for the A block and for the B block (32 B each), issued a whole step ahead of their use
     const uint32_t sk = t >> 5, sc = (t & 31) * 4;
     const double* gA = A.ft + i0 + sc;
     const double* gB = A.ft + j0 + sc;
-    double2 ra0, ra1, rb0, rb1;
+    double2 ra[2][2], rb[2][2];
     auto gload = [&](uint32_t k0) {
-        const uint32_t k = k0 + sk;
-        if (k < A.dim) {
-            const double* pa = gA + (uint64_t)k * A.npad;
-            const double* pb = gB + (uint64_t)k * A.npad;
-            ra0 = *reinterpret_cast<const double2*>(pa);
-            ra1 = *reinterpret_cast<const double2*>(pa + 2);
-            rb0 = *reinterpret_cast<const double2*>(pb);
-            rb1 = *reinterpret_cast<const double2*>(pb + 2);
-        } else {
-            ra0 = ra1 = rb0 = rb1 = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t k = k0 + sk + 8 * h;
+            if (k < A.dim) {
+                const double* pa = gA + (uint64_t)k * A.npad;
+                const double* pb = gB + (uint64_t)k * A.npad;
+                ra[h][0] = *reinterpret_cast<const double2*>(pa);
+                ra[h][1] = *reinterpret_cast<const double2*>(pa + 2);
+                rb[h][0] = *reinterpret_cast<const double2*>(pb);
+                rb[h][1] = *reinterpret_cast<const double2*>(pb + 2);
+            } else {
+                ra[h][0] = ra[h][1] = rb[h][0] = rb[h][1] = make_double2(0.0, 0.0);
+            }
         }
     };
     auto sstore = [&](uint32_t buf) {
-        double* s = stage + buf * kStageDoubles + sk * kRowStride;
-        *reinterpret_cast<double2*>(s + sc) = ra0;
-        *reinterpret_cast<double2*>(s + sc + 2) = ra1;
-        *reinterpret_cast<double2*>(s + TM + sc) = rb0;
-        *reinterpret_cast<double2*>(s + TM + sc + 2) = rb1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double* s = stage + buf * kStageDoubles + (sk + 8 * h) * kRowStride;
+            *reinterpret_cast<double2*>(s + sc) = ra[h][0];
+            *reinterpret_cast<double2*>(s + sc + 2) = ra[h][1];
+            *reinterpret_cast<double2*>(s + TM + sc) = rb[h][0];
+            *reinterpret_cast<double2*>(s + TM + sc + 2) = rb[h][1];
+        }
     };
 
     gload(0);
@@ -104,20 +113,25 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
         const bool more = k0 + KC < A.dim;
         if (more) gload(k0 + KC);
         const double* s = stage + cur * kStageDoubles;
-#pragma unroll
-        for (int ks = 0; ks < KC / 4; ++ks) {
+        // fragments of k-step ks+1 are read from LDS while the 16 MFMAs of k-step ks issue
+        double fa[2][4], fb[2][4];
+        auto frag = [&](int ks, double (&a)[4], double (&b)[4]) {
             const double* srow = s + (ks * 4 + lg) * kRowStride;
-            double a[4], b[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 a[m] = srow[wr * 64 + m * 16 + lc];
                 b[m] = srow[TM + wc * 64 + m * 16 + lc];
             }
+        };
+        frag(0, fa[0], fb[0]);
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            if (ks + 1 < KC / 4) frag(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks & 1][m], fb[ks & 1][n], acc[m][n], 0, 0, 0);
         }
         if (more) sstore(cur ^ 1);
         __syncthreads();
@@ -159,6 +173,8 @@ int launch_gram(po_ctx* ctx, const po_tile_args& a, const double* norms, const u
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
     const size_t shmem = 2 * kStageDoubles * sizeof(double);
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tile_kernel<METRIC, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tile_kernel<METRIC, double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     if (a.out_f32)
         hipLaunchKernelGGL((gram_tile_kernel<METRIC, float>), dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, norms, i8flag);
     else
