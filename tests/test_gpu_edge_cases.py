@@ -1,0 +1,133 @@
+"""Edge cases of the HIP path: tiny and odd sizes, every word-length regime, ragged row ranges, float32
+stores, empty inputs -- against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-6, 1e-12
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import phyloligo_amd as pa
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def pack(contigs):
+    seq = np.frombuffer(b"".join(contigs), dtype=np.uint8)
+    offsets = np.zeros(len(contigs) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(c) for c in contigs])
+    return seq, offsets
+
+
+def assembly(n, seed, lo=50, hi=600, equal=None):
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    p = [.248, .248, .248, .248, .008]
+    return [alpha[rng.choice(5, size=(equal or int(rng.integers(lo, hi))), p=p)].tobytes() for _ in range(n)]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 127, 128, 129, 255, 257])
+@pytest.mark.parametrize("metric", ["Eucl", "JSD", "BC", "SC", "KT"])
+def test_sizes_around_tile_edges(ctx, n, metric):
+    from oracle import phyloligo_oracle as po
+    if metric == "KT" and n > 129:
+        pytest.skip("O(D^2) oracle")
+    pattern = "111" if metric in ("KT", "SC") else "1111"
+    contigs = assembly(n, 100 + n)
+    seq, offsets = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, offsets, pattern, "both")
+    oc, ot = po.compute_counts(contigs, pattern, "both")
+    assert np.array_equal(counts.astype(np.int64), oc)
+    want = po.pairwise_block(po.counts_to_frequencies(oc, ot), metric)
+    got = ctx.pairwise(counts, totals, metric)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-9 if metric == "SC" else ATOL, equal_nan=True)
+    if n > 2:
+        lo, hi = 1, n - 1            # odd row offset, odd leading dimension when n is odd
+        part = ctx.pairwise(counts, totals, metric, row_begin=lo, row_end=hi)
+        np.testing.assert_allclose(part, want[lo:hi], rtol=RTOL, atol=1e-9 if metric == "SC" else ATOL, equal_nan=True)
+    got32 = ctx.pairwise(counts, totals, metric, dtype="float32")
+    np.testing.assert_array_equal(got32, got.astype(np.float32))
+
+
+@pytest.mark.parametrize("pattern", ["1", "11", "111", "11111", "111111", "1111111", "11111111", "101", "1001001"])
+def test_every_word_length_regime(ctx, pattern):
+    """dim = 4 .. 65 536: padded operand rows (dim < 8), LDS histograms, the global-atomic histogram (k = 8)."""
+    from oracle import phyloligo_oracle as po
+    k = pattern.count("1")
+    n = 40 if k >= 7 else 150
+    contigs = assembly(n, 7 + k, lo=100, hi=5000) + [b"", b"ACGT"]
+    seq, offsets = pack(contigs)
+    for strand in ("both", "minus"):
+        counts, totals = ctx.count_profiles(seq, offsets, pattern, strand)
+        oc, ot = po.compute_counts(contigs, pattern, strand)
+        assert np.array_equal(counts.astype(np.int64), oc), (pattern, strand)
+        assert np.array_equal(totals.astype(np.int64), ot)
+    freq = po.counts_to_frequencies(oc, ot)
+    for metric in ("Eucl", "JSD", "BC"):
+        want = po.pairwise_block(freq, metric)
+        got = ctx.pairwise(counts, totals, metric)
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL, equal_nan=True)
+        gen = ctx.pairwise(counts, totals, metric, table_path=False)
+        np.testing.assert_allclose(gen, want, rtol=RTOL, atol=ATOL, equal_nan=True)
+
+
+@pytest.mark.parametrize("metric", ["JSD", "BC", "Eucl"])
+def test_equal_total_blocks_with_ragged_edges(ctx, metric):
+    """Fast-path tiles at the matrix edge (N not a multiple of 128), row blocks cutting through tiles."""
+    from oracle import phyloligo_oracle as po
+    contigs = assembly(300, 5, equal=700)
+    contigs = [c.replace(b"N", b"A") for c in contigs]            # all totals equal
+    seq, offsets = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, offsets, "1111", "both")
+    assert len(set(totals.tolist())) == 1
+    oc, ot = po.compute_counts(contigs, "1111", "both")
+    want = po.pairwise_block(po.counts_to_frequencies(oc, ot), metric)
+    got, st = ctx.pairwise(counts, totals, metric, want_stats=True)
+    assert st["kernel_id"] in (4, 6, 7)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+    assert np.array_equal(got, got.T)
+    for lo, hi in ((0, 1), (5, 133), (127, 300), (299, 300)):
+        np.testing.assert_allclose(ctx.pairwise(counts, totals, metric, row_begin=lo, row_end=hi), want[lo:hi],
+                                   rtol=RTOL, atol=ATOL)
+
+
+def test_empty_and_degenerate_inputs(ctx):
+    import phyloligo_amd as pa
+    counts, totals = ctx.count_profiles(np.zeros(0, np.uint8), np.zeros(1, np.uint64), "1111", "both")
+    assert counts.shape == (0, 256) and totals.shape == (0,)
+    assert ctx.pairwise(counts, totals, "JSD").shape == (0, 0)
+    seq, offsets = pack([b"", b"", b"NNNN"])
+    counts, totals = ctx.count_profiles(seq, offsets, "1111", "both")
+    assert counts.sum() == 0 and totals.sum() == 0
+    for metric, diag, off in (("Eucl", 0.0, 0.0), ("JSD", 0.0, 0.0), ("KT", 0.0, 0.0)):
+        m = ctx.pairwise(counts, totals, metric)
+        assert np.all(np.diag(m) == diag) and m[0, 1] == off
+    bc = ctx.pairwise(counts, totals, "BC")
+    assert np.all(np.diag(bc) == 0.0) and np.isnan(bc[0, 1])          # SciPy: 0/0 off the diagonal
+    assert np.all(np.isnan(ctx.pairwise(counts, totals, "SC")))
+    with pytest.raises(pa.PhyloligoError):
+        ctx.pairwise(counts, totals, "JSD", row_begin=2, row_end=1)
+    with pytest.raises(pa.PhyloligoError):
+        ctx.count_profiles(seq, offsets, "1111", "sideways")
+    with pytest.raises(pa.PhyloligoError):
+        ctx.count_profiles(seq, offsets, "1" * 9, "both")
+
+
+def test_long_records_int8_overflow_and_table_limits(ctx):
+    """Counts above 63 / 127 / 255 switch every fast path off on the device; results stay right."""
+    from oracle import phyloligo_oracle as po
+    rng = np.random.default_rng(3)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for length, expect_max in ((9000, 64), (20000, 128), (45000, 256)):
+        contigs = [alpha[rng.integers(0, 4, size=length)].tobytes() for _ in range(140)]
+        seq, offsets = pack(contigs)
+        counts, totals = ctx.count_profiles(seq, offsets, "1111", "both")
+        assert counts.max() >= expect_max
+        oc, ot = po.compute_counts(contigs, "1111", "both")
+        freq = po.counts_to_frequencies(oc, ot)
+        for metric in ("JSD", "Eucl", "BC"):
+            np.testing.assert_allclose(ctx.pairwise(counts, totals, metric), po.pairwise_block(freq, metric),
+                                       rtol=RTOL, atol=ATOL)
