@@ -54,7 +54,8 @@ typedef enum po_status {
 typedef enum po_strand { PO_STRAND_BOTH = 0, PO_STRAND_PLUS = 1, PO_STRAND_MINUS = 2 } po_strand;
 
 /* -d/--distance choices, bin/phyloligo.py:1012; functions in core/phylodist.py:36-85 */
-typedef enum po_metric { PO_EUCL = 0, PO_JSD = 1, PO_KT = 2, PO_BC = 3, PO_SC = 4 } po_metric;
+typedef enum po_metric { PO_EUCL = 0, PO_JSD = 1, PO_KT = 2, PO_BC = 3, PO_SC = 4,
+                         PO_KL = 5 /* Kount.py only (po_profile_distances), bin/Kount.py:69-85 */ } po_metric;
 
 /* element type of the distance matrix: float64 is what compute_distances_joblib returns
  * (bin/phyloligo.py:364-392); float32 is the container type of the --large memmap variant
@@ -127,6 +128,25 @@ int po_frequencies(po_ctx* ctx, const uint32_t* counts, const uint64_t* totals, 
                    double* freq);
 int po_frequencies_dev(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
                        uint32_t dim, double* d_freq);
+
+/* ---- sliding windows against a prototype (bin/Kount.py, the ContaLocate front end) ----------- *
+ * Profiles of arbitrary, possibly overlapping byte ranges [begins[i], ends[i]) of one sequence buffer:
+ * the windows that make_genome_chunk cuts (bin/Kount.py:343-407), each counted exactly like a record
+ * (cut_sequence_and_count_pattern with the strand handling inside, bin/Kount.py:208-243).
+ * sum_lengths (device form) is an upper bound of sum(ends[i]-begins[i]).                          */
+int po_count_profiles_ranges(po_ctx* ctx, const uint8_t* seq, uint64_t total_bytes, const uint64_t* begins,
+                             const uint64_t* ends, uint64_t n_ranges, const char* pattern, int strand,
+                             uint32_t* counts, uint64_t* totals);
+int po_count_profiles_ranges_dev(po_ctx* ctx, const uint8_t* d_seq, uint64_t total_bytes, const uint64_t* d_begins,
+                                 const uint64_t* d_ends, uint64_t n_ranges, uint64_t sum_lengths, const char* pattern,
+                                 int strand, uint32_t* d_counts, uint64_t* d_totals);
+/* Distance of every profile to ONE prototype frequency vector proto[dim] (compute_distance_joblib,
+ * bin/Kount.py:322-330): PO_JSD / PO_EUCL / PO_KL of bin/Kount.py:69-123 WITHOUT their x1000 display
+ * scaling (the host mirror applies it).  out[n] float64.                                           */
+int po_profile_distances(po_ctx* ctx, const uint32_t* counts, const uint64_t* totals, uint64_t n, uint32_t dim,
+                         const double* proto, int metric, double* out);
+int po_profile_distances_dev(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
+                             uint32_t dim, const double* d_proto, int metric, double* d_out);
 
 /* ---- stage 2: pairwise matrix ----------------------------------------------------------- *
  * Replaces compute_distances_joblib (bin/phyloligo.py:364-392) = sklearn pairwise_distances

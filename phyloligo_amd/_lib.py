@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libphyloligo_amd.so")
 PO_OK, PO_EINVAL, PO_ENODEV, PO_ENOMEM, PO_EHIP, PO_EUNSUPPORTED, PO_EIO = 0, -1, -2, -3, -4, -5, -6
 STRANDS = {"both": 0, "plus": 1, "minus": 2}
 METRICS = {"Eucl": 0, "JSD": 1, "KT": 2, "BC": 3, "SC": 4}
+PO_KL = 5          # Kount.py only (po_profile_distances)
 PO_F64, PO_F32 = 0, 1
 PO_FLAG_NO_SYMMETRY = 1
 PO_FLAG_NO_TABLE_PATH = 2
@@ -57,6 +58,10 @@ SIGNATURES = {
     "po_pattern_info": (_int, [_cp, _c.POINTER(_u32), _c.POINTER(_u32), _c.POINTER(_u64)]),
     "po_count_profiles": (_int, [_vp, _vp, _vp, _u64, _cp, _int, _vp, _vp]),
     "po_count_profiles_dev": (_int, [_vp, _vp, _vp, _u64, _u64, _cp, _int, _vp, _vp]),
+    "po_count_profiles_ranges": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _cp, _int, _vp, _vp]),
+    "po_count_profiles_ranges_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _u64, _cp, _int, _vp, _vp]),
+    "po_profile_distances": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _int, _vp]),
+    "po_profile_distances_dev": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _int, _vp]),
     "po_frequencies": (_int, [_vp, _vp, _vp, _u64, _u32, _vp]),
     "po_frequencies_dev": (_int, [_vp, _vp, _vp, _u64, _u32, _vp]),
     "po_pairwise": (_int, [_vp, _vp, _vp, _u64, _u32, _int, _u64, _u64, _int, _vp, _u64, _u32, _c.POINTER(PoStats)]),

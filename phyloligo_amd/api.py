@@ -104,6 +104,38 @@ class Context:
                                           _np_ptr(counts), _np_ptr(totals)))
         return counts, totals
 
+    def count_profiles_ranges(self, seq, begins, ends, pattern="1111", strand="both"):
+        """Profiles of arbitrary (overlapping) byte ranges [begins[i], ends[i]) of one sequence buffer --
+        Kount.py's sliding windows.  numpy in -> numpy out."""
+        pat = normalise_pattern(pattern)
+        _, _, dim = pattern_info(pat)
+        if strand not in STRANDS:
+            raise _lib.PhyloligoError(_lib.PO_EINVAL, "strand must be one of both/plus/minus (got %r)" % (strand,))
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        begins = np.ascontiguousarray(begins, dtype=np.uint64)
+        ends = np.ascontiguousarray(ends, dtype=np.uint64)
+        n = begins.shape[0]
+        counts = np.zeros((n, dim), dtype=np.uint32)
+        totals = np.zeros((n,), dtype=np.uint64)
+        check(self._lib.po_count_profiles_ranges(self._h, _np_ptr(seq), seq.shape[0], _np_ptr(begins), _np_ptr(ends), n,
+                                                 pat.encode(), STRANDS[strand], _np_ptr(counts), _np_ptr(totals)))
+        return counts, totals
+
+    def profile_distances(self, counts, totals, proto, metric="JSD"):
+        """Distance of every profile to ONE prototype frequency vector (Kount.py's JSD / KL / Eucl, unscaled)."""
+        code = {"Eucl": 0, "JSD": 1, "KL": _lib.PO_KL}.get(metric)
+        if code is None:
+            raise _lib.PhyloligoError(_lib.PO_EINVAL, "metric must be JSD, KL or Eucl (got %r)" % (metric,))
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        totals = np.ascontiguousarray(totals, dtype=np.uint64)
+        proto = np.ascontiguousarray(proto, dtype=np.float64)
+        n, dim = counts.shape
+        assert proto.shape == (dim,)
+        out = np.zeros(n, dtype=np.float64)
+        check(self._lib.po_profile_distances(self._h, _np_ptr(counts), _np_ptr(totals), n, dim, _np_ptr(proto), code,
+                                             _np_ptr(out)))
+        return out
+
     def frequencies(self, counts, totals):
         if _is_torch(counts):
             import torch

@@ -197,7 +197,7 @@ extern "C" int po_count_profiles_dev(po_ctx* ctx, const uint8_t* d_seq, const ui
     PO_REQUIRE(d_seq != nullptr || total_bytes == 0, "po_count_profiles_dev: NULL sequence buffer");
     PO_REQUIRE((reinterpret_cast<uintptr_t>(d_seq) & 15u) == 0, "po_count_profiles_dev: sequence buffer must be 16-byte aligned");
     PO_HIP(hipSetDevice(ctx->device));
-    return po_launch_count(ctx, d_seq, d_offsets, n_seqs, total_bytes, pat, strand, d_counts, d_totals);
+    return po_launch_count(ctx, d_seq, d_offsets, d_offsets + 1, n_seqs, total_bytes, total_bytes, pat, strand, d_counts, d_totals);
 }
 
 extern "C" int po_count_profiles(po_ctx* ctx, const uint8_t* seq, const uint64_t* offsets, uint64_t n_seqs,
@@ -230,7 +230,7 @@ extern "C" int po_count_profiles(po_ctx* ctx, const uint8_t* seq, const uint64_t
     uint64_t* d_tot = reinterpret_cast<uint64_t*>(base + b_seq + b_off + b_cnt);
     if (total) PO_HIP(hipMemcpyAsync(d_seq, seq, total, hipMemcpyHostToDevice, ctx->stream));
     PO_HIP(hipMemcpyAsync(d_off, offsets, (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    rc = po_launch_count(ctx, d_seq, d_off, n_seqs, total, pat, strand, d_cnt, d_tot);
+    rc = po_launch_count(ctx, d_seq, d_off, d_off + 1, n_seqs, total, total, pat, strand, d_cnt, d_tot);
     if (rc) return rc;
     PO_HIP(hipMemcpyAsync(counts, d_cnt, n_seqs * (uint64_t)pat.dim * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     PO_HIP(hipMemcpyAsync(totals, d_tot, n_seqs * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -267,6 +267,103 @@ extern "C" int po_frequencies(po_ctx* ctx, const uint32_t* counts, const uint64_
     rc = po_launch_freq_rowmajor(ctx, d_cnt, d_tot, n, dim, d_frq);
     if (rc) return rc;
     PO_HIP(hipMemcpyAsync(freq, d_frq, b_frq, hipMemcpyDeviceToHost, ctx->stream));
+    PO_HIP(hipStreamSynchronize(ctx->stream));
+    return PO_OK;
+}
+
+// ---- windows (Kount.py) -------------------------------------------------------------------------
+extern "C" int po_count_profiles_ranges_dev(po_ctx* ctx, const uint8_t* d_seq, uint64_t total_bytes,
+                                            const uint64_t* d_begins, const uint64_t* d_ends, uint64_t n_ranges,
+                                            uint64_t sum_lengths, const char* pattern, int strand,
+                                            uint32_t* d_counts, uint64_t* d_totals) {
+    PO_REQUIRE(ctx != nullptr, "po_count_profiles_ranges_dev: ctx is NULL");
+    po_pattern pat;
+    int rc = po_pattern_compile(pattern, &pat);
+    if (rc) return rc;
+    rc = check_strand(strand);
+    if (rc) return rc;
+    if (n_ranges == 0) return PO_OK;
+    PO_REQUIRE(d_begins && d_ends && d_counts && d_totals, "po_count_profiles_ranges_dev: NULL buffer");
+    PO_REQUIRE(d_seq != nullptr || total_bytes == 0, "po_count_profiles_ranges_dev: NULL sequence buffer");
+    PO_REQUIRE((reinterpret_cast<uintptr_t>(d_seq) & 15u) == 0, "po_count_profiles_ranges_dev: sequence buffer must be 16-byte aligned");
+    PO_HIP(hipSetDevice(ctx->device));
+    return po_launch_count(ctx, d_seq, d_begins, d_ends, n_ranges, total_bytes, sum_lengths, pat, strand, d_counts, d_totals);
+}
+
+extern "C" int po_count_profiles_ranges(po_ctx* ctx, const uint8_t* seq, uint64_t total_bytes, const uint64_t* begins,
+                                        const uint64_t* ends, uint64_t n_ranges, const char* pattern, int strand,
+                                        uint32_t* counts, uint64_t* totals) {
+    PO_REQUIRE(ctx != nullptr, "po_count_profiles_ranges: ctx is NULL");
+    po_pattern pat;
+    int rc = po_pattern_compile(pattern, &pat);
+    if (rc) return rc;
+    rc = check_strand(strand);
+    if (rc) return rc;
+    if (n_ranges == 0) return PO_OK;
+    PO_REQUIRE(begins && ends && counts && totals, "po_count_profiles_ranges: NULL buffer");
+    PO_REQUIRE(seq != nullptr || total_bytes == 0, "po_count_profiles_ranges: NULL sequence buffer");
+    uint64_t sum = 0;
+    for (uint64_t i = 0; i < n_ranges; ++i) {
+        PO_REQUIRE(begins[i] <= ends[i] && ends[i] <= total_bytes, "po_count_profiles_ranges: range %llu outside the buffer", (unsigned long long)i);
+        sum += ends[i] - begins[i];
+    }
+    PO_HIP(hipSetDevice(ctx->device));
+    const size_t b_seq = po_round_up(total_bytes + 64, 256);
+    const size_t b_rng = po_round_up(n_ranges * sizeof(uint64_t), 256);
+    const size_t b_cnt = po_round_up(n_ranges * (uint64_t)pat.dim * sizeof(uint32_t), 256);
+    const size_t b_tot = po_round_up(n_ranges * sizeof(uint64_t), 256);
+    rc = po_buf_reserve(ctx, &ctx->ws_io, b_seq + 2 * b_rng + b_cnt + b_tot);
+    if (rc) return rc;
+    uint8_t* base = static_cast<uint8_t*>(ctx->ws_io.p);
+    uint8_t* d_seq = base;
+    uint64_t* d_beg = reinterpret_cast<uint64_t*>(base + b_seq);
+    uint64_t* d_end = reinterpret_cast<uint64_t*>(base + b_seq + b_rng);
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(base + b_seq + 2 * b_rng);
+    uint64_t* d_tot = reinterpret_cast<uint64_t*>(base + b_seq + 2 * b_rng + b_cnt);
+    if (total_bytes) PO_HIP(hipMemcpyAsync(d_seq, seq, total_bytes, hipMemcpyHostToDevice, ctx->stream));
+    PO_HIP(hipMemcpyAsync(d_beg, begins, n_ranges * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    PO_HIP(hipMemcpyAsync(d_end, ends, n_ranges * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = po_launch_count(ctx, d_seq, d_beg, d_end, n_ranges, total_bytes, sum, pat, strand, d_cnt, d_tot);
+    if (rc) return rc;
+    PO_HIP(hipMemcpyAsync(counts, d_cnt, n_ranges * (uint64_t)pat.dim * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PO_HIP(hipMemcpyAsync(totals, d_tot, n_ranges * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PO_HIP(hipStreamSynchronize(ctx->stream));
+    return PO_OK;
+}
+
+extern "C" int po_profile_distances_dev(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
+                                        uint32_t dim, const double* d_proto, int metric, double* d_out) {
+    PO_REQUIRE(ctx != nullptr, "po_profile_distances_dev: ctx is NULL");
+    PO_REQUIRE(metric == PO_EUCL || metric == PO_JSD || metric == PO_KL, "po_profile_distances_dev: metric must be Eucl, JSD or KL (got %d)", metric);
+    if (n == 0) return PO_OK;
+    PO_REQUIRE(d_counts && d_totals && d_proto && d_out && dim > 0, "po_profile_distances_dev: bad argument");
+    PO_HIP(hipSetDevice(ctx->device));
+    return po_launch_profile_distances(ctx, d_counts, d_totals, n, dim, d_proto, metric, d_out);
+}
+
+extern "C" int po_profile_distances(po_ctx* ctx, const uint32_t* counts, const uint64_t* totals, uint64_t n, uint32_t dim,
+                                    const double* proto, int metric, double* out) {
+    PO_REQUIRE(ctx != nullptr, "po_profile_distances: ctx is NULL");
+    PO_REQUIRE(metric == PO_EUCL || metric == PO_JSD || metric == PO_KL, "po_profile_distances: metric must be Eucl, JSD or KL (got %d)", metric);
+    if (n == 0) return PO_OK;
+    PO_REQUIRE(counts && totals && proto && out && dim > 0, "po_profile_distances: bad argument");
+    PO_HIP(hipSetDevice(ctx->device));
+    const size_t b_cnt = po_round_up(n * (uint64_t)dim * sizeof(uint32_t), 256);
+    const size_t b_tot = po_round_up(n * sizeof(uint64_t), 256);
+    const size_t b_pro = po_round_up(dim * sizeof(double), 256);
+    int rc = po_buf_reserve(ctx, &ctx->ws_io, b_cnt + b_tot + b_pro + n * sizeof(double));
+    if (rc) return rc;
+    uint8_t* base = static_cast<uint8_t*>(ctx->ws_io.p);
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(base);
+    uint64_t* d_tot = reinterpret_cast<uint64_t*>(base + b_cnt);
+    double* d_pro = reinterpret_cast<double*>(base + b_cnt + b_tot);
+    double* d_out = reinterpret_cast<double*>(base + b_cnt + b_tot + b_pro);
+    PO_HIP(hipMemcpyAsync(d_cnt, counts, n * (uint64_t)dim * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PO_HIP(hipMemcpyAsync(d_tot, totals, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    PO_HIP(hipMemcpyAsync(d_pro, proto, dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = po_launch_profile_distances(ctx, d_cnt, d_tot, n, dim, d_pro, metric, d_out);
+    if (rc) return rc;
+    PO_HIP(hipMemcpyAsync(out, d_out, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PO_HIP(hipStreamSynchronize(ctx->stream));
     return PO_OK;
 }

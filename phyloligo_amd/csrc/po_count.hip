@@ -53,19 +53,22 @@ __device__ __forceinline__ uint32_t word_index(uint64_t reg, const CountParams& 
     return idx;
 }
 
-__device__ __forceinline__ uint32_t chunks_of(const uint64_t* offsets, uint32_t i) {
-    return (uint32_t)((offsets[i + 1] - offsets[i] + kSpan - 1) / kSpan);
+// record i is bytes [begins[i], ends[i]) of the sequence buffer (contiguous records: ends = begins + 1;
+// sliding windows: arbitrary, overlapping ranges)
+__device__ __forceinline__ uint32_t chunks_of(const uint64_t* begins, const uint64_t* ends, uint32_t i) {
+    return (uint32_t)((ends[i] - begins[i] + kSpan - 1) / kSpan);
 }
 
 // ---- chunks per record, exclusive scan -> chunk_start[n+1]: three small launches ----------------
 // (1) per-1024-record block sums, (2) scan of the block sums, (3) local scan + block offset.
-__global__ __launch_bounds__(256) void scan_block_sums_kernel(const uint64_t* __restrict__ offsets, uint32_t n,
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const uint64_t* __restrict__ begins,
+                                                              const uint64_t* __restrict__ ends, uint32_t n,
                                                               uint32_t* __restrict__ blocksum) {
     __shared__ uint32_t wsum[4];
     const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
     uint32_t s = 0;
     for (uint32_t e = 0; e < 4; ++e)
-        if (base + e < n) s += chunks_of(offsets, base + e);
+        if (base + e < n) s += chunks_of(begins, ends, base + e);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -95,7 +98,8 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ 
     if (t == 0) *total = carry;
 }
 
-__global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restrict__ offsets, uint32_t n,
+__global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restrict__ begins,
+                                                         const uint64_t* __restrict__ ends, uint32_t n,
                                                          const uint32_t* __restrict__ blocksum,
                                                          const uint32_t* __restrict__ total,
                                                          uint32_t* __restrict__ chunk_start) {
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
     const uint32_t base = blockIdx.x * 1024 + t * 4;
     uint32_t c[4], s = 0;
     for (uint32_t e = 0; e < 4; ++e) {
-        c[e] = (base + e < n) ? chunks_of(offsets, base + e) : 0u;
+        c[e] = (base + e < n) ? chunks_of(begins, ends, base + e) : 0u;
         s += c[e];
     }
     part[t] = s;
@@ -126,7 +130,8 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
 // ---- counting: one WAVE per chunk, no workgroup barrier -------------------------------------------
 template <bool LDS_HIST>
 __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restrict__ seq,
-                                                         const uint64_t* __restrict__ offsets,
+                                                         const uint64_t* __restrict__ begins,
+                                                         const uint64_t* __restrict__ ends,
                                                          const uint32_t* __restrict__ chunk_start,
                                                          CountParams P, uint32_t waves_per_block,
                                                          uint32_t* __restrict__ counts,
@@ -150,8 +155,8 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     const uint32_t rec = lo;
     const uint32_t chunk = b - chunk_start[rec];
     const uint32_t rec_chunks = chunk_start[rec + 1] - chunk_start[rec];
-    const uint64_t off = offsets[rec];
-    const int64_t L = (int64_t)(offsets[rec + 1] - off);
+    const uint64_t off = begins[rec];
+    const int64_t L = (int64_t)(ends[rec] - off);
     const int64_t p_lo = (int64_t)chunk * kSpan;                   // window starts [p_lo, p_hi) are ours
     const int64_t p_hi = min(p_lo + (int64_t)kSpan, L);
     const uint64_t a0 = (off + (uint64_t)p_lo) & ~(uint64_t)15;    // 16 B aligned staging origin
@@ -280,12 +285,12 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
 
 }  // namespace
 
-int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets, uint64_t n_seqs,
-                    uint64_t total_bytes, const po_pattern& pat, int strand, uint32_t* d_counts,
+int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins, const uint64_t* d_ends, uint64_t n_seqs,
+                    uint64_t total_bytes, uint64_t sum_lengths, const po_pattern& pat, int strand, uint32_t* d_counts,
                     uint64_t* d_totals) {
     if (n_seqs == 0) return PO_OK;
     if (n_seqs >= (1ull << 31)) { po_set_error("too many records (%llu)", (unsigned long long)n_seqs); return PO_EUNSUPPORTED; }
-    const uint64_t max_chunks = total_bytes / kSpan + n_seqs;
+    const uint64_t max_chunks = sum_lengths / kSpan + n_seqs;
     if (max_chunks >= (1ull << 31)) { po_set_error("input too large for one launch"); return PO_EUNSUPPORTED; }
 
     const uint32_t nb = (uint32_t)((n_seqs + 1023) / 1024);
@@ -300,11 +305,11 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets
     PO_HIP(hipMemsetAsync(d_counts, 0, n_seqs * (uint64_t)pat.dim * sizeof(uint32_t), ctx->stream));
     PO_HIP(hipMemsetAsync(d_totals, 0, n_seqs * sizeof(uint64_t), ctx->stream));
 
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_offsets, (uint32_t)n_seqs, blocksum);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_begins, d_ends, (uint32_t)n_seqs, blocksum);
     PO_CHECK_LAUNCH("scan_block_sums_kernel");
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, blocksum, nb, total);
     PO_CHECK_LAUNCH("scan_sums_kernel");
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_offsets, (uint32_t)n_seqs, blocksum, total, chunk_start);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_begins, d_ends, (uint32_t)n_seqs, blocksum, total, chunk_start);
     PO_CHECK_LAUNCH("scan_apply_kernel");
 
     CountParams P;
@@ -328,9 +333,9 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets
     if (lds_hist) {
         auto k = count_kernel<true>;
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), shmem, ctx->stream, d_seq, d_offsets, chunk_start, P, wpb, d_counts, tot);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), shmem, ctx->stream, d_seq, d_begins, d_ends, chunk_start, P, wpb, d_counts, tot);
     } else {
-        hipLaunchKernelGGL(count_kernel<false>, dim3(grid), dim3(kThreads), shmem, ctx->stream, d_seq, d_offsets, chunk_start, P, wpb, d_counts, tot);
+        hipLaunchKernelGGL(count_kernel<false>, dim3(grid), dim3(kThreads), shmem, ctx->stream, d_seq, d_begins, d_ends, chunk_start, P, wpb, d_counts, tot);
     }
     PO_CHECK_LAUNCH("count_kernel");
     return PO_OK;

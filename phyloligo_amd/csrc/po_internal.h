@@ -80,9 +80,13 @@ struct po_pattern {
 int po_pattern_compile(const char* pattern, po_pattern* out);
 
 // ---- kernels (one launcher per translation unit) -----------------------------------------
-int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets, uint64_t n_seqs,
-                    uint64_t total_bytes, const po_pattern& pat, int strand, uint32_t* d_counts,
+// record i = bytes [d_begins[i], d_ends[i]) of d_seq; sum_lengths >= sum of the record lengths
+int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins, const uint64_t* d_ends, uint64_t n_seqs,
+                    uint64_t total_bytes, uint64_t sum_lengths, const po_pattern& pat, int strand, uint32_t* d_counts,
                     uint64_t* d_totals);
+// distance of every profile to one prototype frequency vector (Kount.py); metric PO_EUCL / PO_JSD / PO_KL
+int po_launch_profile_distances(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                                const double* d_proto, int metric, double* d_out);
 
 // Working layout of stage 2: Ft[d][npad] = counts[n][d] / totals[n] (float64, zero padded).
 // skip_if_le127 (may be NULL): device word with the largest count; the kernel does nothing when it is <= 127

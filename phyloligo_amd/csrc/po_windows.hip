@@ -1,0 +1,54 @@
+// Distance of many profiles (sliding windows) to ONE prototype profile.
+//
+// Replaces the per-window Python calls of the ContaLocate front end
+//   compute_distance_joblib -> JSD / KL / Eucl   (/root/reference/phylopackage/bin/Kount.py:322-330, :69-123)
+// (without the x1000 display scaling of :96 and :123, which the host mirror applies).  Work is N_windows x D
+// -- five orders of magnitude below the all-by-all matrix -- so this is one wave per window with the
+// library float64 log, in the reference's own direct form (term by term, NaN/Inf terms dropped as
+// posdef_check_value does, :64-66), reduced over the wave in a fixed order.
+#include "po_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void profile_distance_kernel(const uint32_t* __restrict__ counts,
+                                                               const unsigned long long* __restrict__ totals, uint64_t n,
+                                                               uint32_t dim, const double* __restrict__ proto, int metric,
+                                                               double* __restrict__ out) {
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (w >= n) return;
+    const unsigned long long tot = totals[w];
+    const double inv = tot ? 1.0 / (double)tot : 0.0;
+    const uint32_t* row = counts + w * dim;
+    double acc = 0.0;
+    for (uint32_t d = lane; d < dim; d += 64) {
+        const double a = tot ? (double)row[d] / (double)tot : 0.0;     // count2freq: count / kword_count
+        const double b = proto[d];
+        if (metric == PO_EUCL) {
+            const double x = a - b;
+            acc += x * x;
+        } else if (metric == PO_KL) {                                    // a ln(a/b); NaN / Inf terms are dropped
+            if (a > 0.0 && b > 0.0) acc += a * log(a / b);
+        } else {                                                         // JSD: 1/2 (KL(a,h) + KL(b,h)), h = (a+b)/2
+            const double h = 0.5 * (a + b);
+            double t = 0.0;
+            if (a > 0.0) t += a * log(a / h);
+            if (b > 0.0) t += b * log(b / h);
+            acc += t;
+        }
+    }
+    (void)inv;
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) out[w] = (metric == PO_EUCL) ? sqrt(acc) : (metric == PO_JSD ? 0.5 * acc : acc);
+}
+
+}  // namespace
+
+int po_launch_profile_distances(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                                const double* d_proto, int metric, double* d_out) {
+    if (n == 0) return PO_OK;
+    hipLaunchKernelGGL(profile_distance_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, ctx->stream, d_counts,
+                       reinterpret_cast<const unsigned long long*>(d_totals), n, dim, d_proto, metric, d_out);
+    PO_CHECK_LAUNCH("profile_distance_kernel");
+    return PO_OK;
+}

@@ -122,3 +122,19 @@ def test_synthetic_generators_agree():
     part, _ = synthetic.contig_bytes_range(20, 100, 5, 7, 13)
     assert np.array_equal(seq[700:1300], part)
     assert b"".join(po.synthetic_contigs(20, 100, seed=5)) == seq.tobytes()
+
+
+def test_kount_window_rules_match_reference(golden_dir):
+    """Host logic of the Kount mirror: which windows exist and the coordinates that are displayed."""
+    from phyloligo_amd import kount
+    g = np.load(os.path.join(golden_dir, "kount.npz"))
+    titles, seqs = po.parse_fasta(g["genome_fasta"].tobytes())
+    ids, d0, d1, lens = [], [], [], []
+    for t, s in zip(titles, seqs):
+        for start, a, b in kount.record_windows(len(s), 1000, 200):
+            ids.append(t.split(None, 1)[0]); d0.append(a); d1.append(b); lens.append(min(len(s), start + 1000) - start)
+    assert ids == list(g["win_id_1111_both"]) and d0 == list(g["win_start_1111_both"]) and d1 == list(g["win_stop_1111_both"])
+    assert lens == list(g["win_len_1111_both"])
+    p = kount.get_cmd(["-i", "x.fa"])
+    assert (p.k, p.pattern, p.windows_size, p.windows_step, p.dist, p.strand, p.n_max_freq_in_windows) == \
+        (4, None, 5000, 500, "JSD", "both", 0.4)
