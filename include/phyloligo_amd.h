@@ -68,7 +68,7 @@ typedef enum po_dtype { PO_F64 = 0, PO_F32 = 1 } po_dtype;
 
 #define PO_FLAG_NO_TABLE_PATH 2u /* general kernels only: no integer-sum table kernel for JSD record blocks with
                                    equal word totals, no exact int8-MFMA kernel for Eucl profiles <= 127,
-                                   no packed-byte SAD kernel for BC                                        */
+                                   no packed-byte SAD kernel for BC, no int8-MFMA kernel for KT           */
 
 /* Filled by po_pairwise* when non-NULL.  Times are HIP-event times on the context's stream;
  * asking for them makes the call synchronise. */
@@ -87,6 +87,7 @@ typedef struct po_stats {
 #define PO_KERNEL_MFMA_F64_GRAM 3u
 #define PO_KERNEL_MFMA_I8_GRAM 4u  /* exact int8 kernel when every count <= 127, else the float64 one */
 #define PO_KERNEL_VALU_KT 5u
+#define PO_KERNEL_MFMA_I8_KT 8u /* Kendall tau as an int8-MFMA Gram over pair-sign vectors (dim <= 256) */
 #define PO_KERNEL_SAD_BC 7u    /* packed-byte SAD kernel (equal-total blocks) + general kernel for the rest */
 #define PO_KERNEL_LUT_JSD 6u   /* integer-sum table kernel + general kernel for the remaining tiles */
 

@@ -381,6 +381,10 @@ static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
     } else {
         rc = po_buf_reserve(ctx, &ctx->ws_aux, n * (uint64_t)dim * sizeof(uint32_t));
         if (rc) return rc;
+        if (po_kt_mfma_supported(dim)) {      // uint8 ranks + word-pair items of the MFMA kernel
+            rc = po_buf_reserve(ctx, &ctx->ws_freq, po_kt_mfma_workspace(n, dim));
+            if (rc) return rc;
+        }
     }
     if (metric == PO_JSD) {
         rc = po_logtab_init(ctx);
@@ -473,6 +477,12 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, nullptr, lessrank, rowstat);
     }
     if (rc) return rc;
+    uint32_t kt_items = 0, kt_full_rounds = 0;
+    const bool kt_mfma = metric == PO_KT && po_kt_mfma_supported(dim) && !(flags & PO_FLAG_NO_TABLE_PATH);
+    if (kt_mfma) {
+        rc = po_launch_kt_mfma_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, &kt_items, &kt_full_rounds);
+        if (rc) return rc;
+    }
     if (metric == PO_EUCL || metric == PO_SC) {
         rc = po_launch_gram_norms(ctx, ft, dim, npad, rowstat, i8flag);
         if (rc) return rc;
@@ -538,7 +548,10 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
                 kid = i8flag ? PO_KERNEL_MFMA_I8_GRAM : PO_KERNEL_MFMA_F64_GRAM;
                 break;
             case PO_SC: rc = po_launch_gram_f64(ctx, PO_SC, a, nullptr, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
-            case PO_KT: rc = po_launch_kt(ctx, lessrank, n, dim, a, &tiles); kid = PO_KERNEL_VALU_KT; break;
+            case PO_KT:
+                if (kt_mfma) { rc = po_launch_kt_mfma_tiles(ctx, a, ctx->ws_freq.p, kt_items, kt_full_rounds, &tiles); kid = PO_KERNEL_MFMA_I8_KT; }
+                else { rc = po_launch_kt(ctx, lessrank, n, dim, a, &tiles); kid = PO_KERNEL_VALU_KT; }
+                break;
         }
         if (rc) return rc;
     }

@@ -146,4 +146,12 @@ int po_launch_ranks(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq,
 int po_launch_kt(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, const po_tile_args& a,
                  uint64_t* tiles);
 
+// Kendall on the int8 matrix cores (dim <= 256)
+bool po_kt_mfma_supported(uint32_t dim);
+size_t po_kt_mfma_workspace(uint64_t n, uint32_t dim);
+int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, uint64_t npad, void* ws,
+                           uint32_t* n_items_out, uint32_t* n_full_rounds_out);
+int po_launch_kt_mfma_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint32_t n_items, uint32_t n_full_rounds,
+                            uint64_t* tiles);
+
 static inline uint64_t po_round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }

@@ -1,0 +1,269 @@
+// Stage 2, Kendall tau on the int8 matrix cores (word spaces of at most 256 words, i.e. k <= 4).
+//
+// Same quantity as kt_tile_kernel (phylodist.KT, /root/reference/phylopackage/core/phylodist.py:71-74; see
+// po_kt.hip for the tie algebra): per record pair only
+//     S = sum_{p<q} sgn(x_p - x_q) sgn(y_p - y_q) = < sigma(x), sigma(y) >
+// is needed, the dot product of the two records' PAIR-SIGN vectors sigma(x)_{(p,q)} = sgn(x_q - x_p) in
+// {-1,0,+1}^{D(D-1)/2}.  That is a Gram matrix over int8 data: exactly what v_mfma_i32_32x32x32_i8 computes.
+// The sign vectors (32 640 bytes per record at D = 256) are never materialised in HBM: a 128 x 128 tile
+// keeps the 256 records' rank rows (uint8, 64 KiB) in LDS; each lane owns one record and expands, per
+// K step of 32 word pairs, 2 x 16 signs with packed 16-bit arithmetic (v_pk_sub_i16, clamp to [-1,1],
+// v_perm_b32 repack), writes them to a double-buffered LDS sign tile, and the four waves feed them to the
+// matrix cores.  The workgroup is wave-specialised: waves 0-7 (two lanes per record) are producers that
+// expand round r+1 while waves 8-15, which share their SIMDs, are consumers feeding round r to the MFMAs
+// (64 x 32 outputs each, plus the transposed product for the mirrored output tile, which is free because
+// the kernel is bound by the VALU sign expansion, not by the matrix cores).  Word pairs are enumerated as
+// items (p, block of 16 consecutive q): 2 160 items for D = 256, 6 % padding; blocks lying wholly above
+// their p need no masking and form the hot loop.  Measured: 1.1e10 pairs/s at N = 50 000, D = 256 (112 ms),
+// against 1.3e8 pairs/s for the O(D^2)-per-pair VALU kernel of po_kt.hip.
+#include "po_tiles.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+constexpr int TM = 128, TN = 128;
+constexpr int kThreads = 1024;              // waves 0-7 expand signs (two lanes per record), waves 8-15 run the MFMAs
+constexpr int KS = 4;                       // K steps (32 word pairs each) per barrier
+constexpr int kSigStride = KS * 32 + 16;    // bytes per record in the sign tile (+16: conflict-free b128 rows)
+
+__global__ __launch_bounds__(256) void rank8_kernel(const uint32_t* __restrict__ lessrank, uint64_t n, uint32_t dim,
+                                                    uint64_t npad, uint8_t* __restrict__ rank8) {
+    const uint64_t total = npad * dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
+        rank8[i] = (i / dim < n) ? (uint8_t)lessrank[i] : (uint8_t)0;
+}
+
+// 4 packed bytes of ranks -> 4 packed sign bytes of (x_q - x_p).  one2 / mone2 = {1,1} / {-1,-1} in VGPRs
+// (packed 16-bit immediates are not inline constants); the clamps are pinned to v_pk_min/max_i16 because
+// hipcc otherwise scalarises them into compare + select pairs.
+__device__ __forceinline__ uint32_t sign4(uint32_t w, uint32_t xp2, uint32_t one2, uint32_t mone2) {
+    uint32_t lo = w & 0x00FF00FFu, hi = (w >> 8) & 0x00FF00FFu;
+    asm("v_pk_sub_i16 %0, %0, %1\n\tv_pk_min_i16 %0, %0, %2\n\tv_pk_max_i16 %0, %0, %3" : "+v"(lo) : "v"(xp2), "v"(one2), "v"(mone2));
+    asm("v_pk_sub_i16 %0, %0, %1\n\tv_pk_min_i16 %0, %0, %2\n\tv_pk_max_i16 %0, %0, %3" : "+v"(hi) : "v"(xp2), "v"(one2), "v"(mone2));
+    // bytes: out0 = lo.b0, out1 = hi.b0, out2 = lo.b2, out3 = hi.b2   (perm: src1 = bytes 0-3, src0 = bytes 4-7)
+    return __builtin_amdgcn_perm(hi, lo, 0x06020400u);
+}
+
+template <typename OUT>
+__global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args A, const uint8_t* __restrict__ rank8,
+                                                                   const uint16_t* __restrict__ items, uint32_t n_items,
+                                                                   uint32_t n_full_rounds) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t rstride = A.dim + 16;                               // rank row stride in LDS (bytes)
+    unsigned char* ranks = smem;                                       // [256][rstride]
+    unsigned char* sigma = smem + ((256 * rstride + 15) & ~15u);       // [2][256][kSigStride]
+    uint16_t* litems = reinterpret_cast<uint16_t*>(sigma + 2 * 256 * kSigStride);   // [n_items] word-pair items
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t lane = t & 63, wave = t >> 6;
+    const bool producer = wave < 8;                                    // wave-uniform role
+    const uint32_t cw_ = wave & 7, wr = cw_ >> 2, wc = cw_ & 3;        // consumer wave -> 64 rows x 32 columns of the tile
+    const uint32_t half = __builtin_amdgcn_readfirstlane(t >> 8) & 1;  // producer wave: which half of a round's items (uniform)
+    const uint32_t lr = lane & 31, lh = lane >> 5;
+
+    uint32_t ti, tj;
+    po_tile_coords(A, TM, blockIdx.x, ti, tj);
+    const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
+    const bool mirror = po_tile_mirrors(A, ti, tj);
+
+    // ---- producer lane = one record: rank row into LDS (rows 0..127 = tile rows, 128..255 = tile columns) ----
+    if (producer && half == 0) {
+        const uint64_t rec = (t < 128) ? i0 + t : j0 + (t - 128);      // < npad: padded rows are zero
+        const uint8_t* src = rank8 + rec * A.dim;
+        unsigned char* dst = ranks + t * rstride;
+        if ((A.dim & 15u) == 0) {
+            for (uint32_t d = 0; d < A.dim; d += 16) *reinterpret_cast<uint4*>(dst + d) = *reinterpret_cast<const uint4*>(src + d);
+        } else {
+            for (uint32_t d = 0; d < A.dim; ++d) dst[d] = src[d];
+            for (uint32_t d = A.dim; d < ((A.dim + 15u) & ~15u); ++d) dst[d] = 0;
+        }
+    }
+    for (uint32_t i = t; i < n_items; i += kThreads) litems[i] = items[i];
+    __syncthreads();
+
+    v16i g[2], gt[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { g[m][e] = 0; gt[m][e] = 0; }
+
+    // sign expansion of KS K-steps (2 items each) for this lane's record into sign buffer `buf`.
+    // MASKED = false for the rounds whose 16-q blocks lie entirely above their p (no byte to suppress).
+    const unsigned char* myrank = ranks + (t & 255) * rstride;
+    uint32_t one2, mone2;
+    asm volatile("v_mov_b32 %0, 0x00010001" : "=v"(one2));
+    asm volatile("v_mov_b32 %0, -1" : "=v"(mone2));
+    auto expand = [&](uint32_t item0, uint32_t buf, bool masked) {
+        unsigned char* dst = sigma + (buf * 256 + (t & 255)) * kSigStride;
+        // this wave's KS item codes (wave uniform -> scalar registers)
+        const uint2 c2 = *reinterpret_cast<const uint2*>(litems + item0 + half * KS);
+        const uint32_t cw[2] = {(uint32_t)__builtin_amdgcn_readfirstlane(c2.x), (uint32_t)__builtin_amdgcn_readfirstlane(c2.y)};
+        // all LDS reads of the lane's KS items first (the sign-tile stores below may alias them for the
+        // compiler, which would otherwise serialise read -> compute -> store item by item)
+        uint32_t pp[KS], qq[KS], xps[KS];
+        uint4 ws[KS];
+#pragma unroll
+        for (int it4 = 0; it4 < KS; ++it4) {                           // this lane's half of the round's 2 KS items
+            const uint32_t code = (cw[it4 >> 1] >> (16 * (it4 & 1))) & 0xFFFFu;   // wave uniform: (p << 8) | qblock
+            pp[it4] = code >> 8;
+            qq[it4] = code & 0xFFu;
+            xps[it4] = myrank[pp[it4]];
+            ws[it4] = *reinterpret_cast<const uint4*>(myrank + qq[it4] * 16);
+        }
+#pragma unroll
+        for (int it4 = 0; it4 < KS; ++it4) {
+            const uint32_t it = half * KS + it4;
+            const uint32_t p = pp[it4], qb = qq[it4];
+            const uint32_t xp2 = xps[it4] | (xps[it4] << 16);
+            const uint4 w = ws[it4];
+            uint32_t sg[4] = {sign4(w.x, xp2, one2, mone2), sign4(w.y, xp2, one2, mone2),
+                              sign4(w.z, xp2, one2, mone2), sign4(w.w, xp2, one2, mone2)};
+            if (masked) {     // only q in (p, dim) counts: bytes [first, last) of the block survive (uniform)
+                const uint32_t q0 = qb * 16;
+                const uint32_t first = (p + 1 > q0) ? min(p + 1 - q0, 16u) : 0u;
+                const uint32_t last = (A.dim - q0 < 16u) ? A.dim - q0 : 16u;
+#pragma unroll
+                for (uint32_t wi = 0; wi < 4; ++wi) {
+                    const uint32_t lo_b = first > 4 * wi ? min(first - 4 * wi, 4u) : 0u;    // leading bytes to clear
+                    const uint32_t hi_b = last > 4 * wi ? min(last - 4 * wi, 4u) : 0u;      // bytes before `last` kept
+                    const uint32_t keep_lo = lo_b >= 4 ? 0u : (0xFFFFFFFFu << (8 * lo_b));
+                    const uint32_t keep_hi = hi_b >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi_b)) - 1u);
+                    sg[wi] &= keep_lo & keep_hi;
+                }
+            }
+            *reinterpret_cast<uint4*>(dst + it * 16) = make_uint4(sg[0], sg[1], sg[2], sg[3]);
+        }
+    };
+
+    const uint32_t n_rounds = n_items / (2 * KS);                       // items are padded to a multiple of 2 KS
+    auto consume = [&](uint32_t buf) {
+        const unsigned char* sa = sigma + (buf * 256 + wr * 64 + lr) * kSigStride + 16 * lh;
+        const unsigned char* sb = sigma + (buf * 256 + 128 + wc * 32 + lr) * kSigStride + 16 * lh;
+        v4i a[KS][2], b[KS];                                           // all fragment reads of the round in flight at once
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a[ks][m] = *reinterpret_cast<const v4i*>(sa + m * 32 * kSigStride + ks * 32);
+            b[ks] = *reinterpret_cast<const v4i*>(sb + ks * 32);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                g[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks][m], b[ks], g[m], 0, 0, 0);
+                if (mirror) gt[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[ks], a[ks][m], gt[m], 0, 0, 0);
+            }
+        }
+    };
+    // rounds [0, n_full_rounds) hold only whole blocks (no masking code in the hot loop), the rest may be partial.
+    // Producer waves write round r+1 into one sign buffer while the consumer waves, which share their SIMDs,
+    // feed round r from the other buffer to the matrix cores: VALU expansion and MFMA overlap.
+    if (producer) expand(0, 0, n_full_rounds == 0);
+    __syncthreads();
+    for (uint32_t r = 0; r < n_rounds; ++r) {
+        const uint32_t buf = r & 1;
+        if (producer) {
+            if (r + 1 < n_full_rounds) expand((r + 1) * 2 * KS, buf ^ 1, false);
+            else if (r + 1 < n_rounds) expand((r + 1) * 2 * KS, buf ^ 1, true);
+        } else {
+            consume(buf);
+        }
+        __syncthreads();
+    }
+    if (producer) return;
+
+    // ---- epilogue: tau = S / sqrt((T - t_r)(T - t_c)), KT = 1 - (1 - tau), 0 when a factor vanishes -----
+    const double T = 0.5 * (double)A.dim * ((double)A.dim - 1.0);
+    const double* ties = A.rowstat + 3 * A.npad;
+    auto emit = [&](const v16i& acc, uint64_t r0, uint64_t c0, bool swap) {
+        OUT* dst = static_cast<OUT*>(swap ? A.mirror : A.out);
+        const uint64_t ld = swap ? A.ld_mirror : A.ld_out;
+        const uint64_t row_off = swap ? A.col_begin : A.row_begin, col_off = swap ? A.row_begin : A.col_begin;
+        const uint64_t row_hi = min(A.n, swap ? A.col_end : A.row_end), col_hi = min(A.n, swap ? A.row_end : A.col_end);
+        const uint64_t c = c0 + lr;
+        const double dc = T - ties[min(c, A.npad - 1)];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const uint64_t rr = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            const double dr = T - ties[min(rr, A.npad - 1)];
+            double v;
+            if (dr == 0.0 || dc == 0.0) {
+                v = 1.0 - 1.0;
+            } else {
+                const double tau = (double)acc[reg] / sqrt(dr * dc);
+                v = 1.0 - (1.0 - tau);
+            }
+            if (rr >= row_off && rr < row_hi && c >= col_off && c < col_hi) dst[(rr - row_off) * ld + (c - col_off)] = (OUT)v;
+        }
+    };
+    const uint64_t ri = i0 + wr * 64, cj = j0 + wc * 32;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        emit(g[m], ri + m * 32, cj, false);
+        if (mirror) emit(gt[m], cj, ri + m * 32, true);
+    }
+}
+
+}  // namespace
+
+bool po_kt_mfma_supported(uint32_t dim) { return dim <= 256; }
+
+size_t po_kt_mfma_workspace(uint64_t n, uint32_t dim) {
+    const uint64_t npad = po_round_up(n ? n : 1, 128);
+    const size_t items = (size_t)dim * (dim / 16 + 2) + 16;
+    return npad * dim + items * sizeof(uint16_t) + 512;
+}
+
+// ws layout: rank8[npad][dim] | items.  Returns the number of (padded) items.
+int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, uint64_t npad, void* ws,
+                           uint32_t* n_items_out, uint32_t* n_full_rounds_out) {
+    uint8_t* rank8 = static_cast<uint8_t*>(ws);
+    uint16_t* d_items = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(ws) + ((npad * dim + 255) & ~(uint64_t)255));
+    hipLaunchKernelGGL(rank8_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_lessrank, n, dim, npad, rank8);
+    PO_CHECK_LAUNCH("rank8_kernel");
+    // word pairs as items (p, block of 16 q): every block that contains a q in (p, dim).  Blocks lying wholly
+    // inside (p, dim) come first, in whole rounds; the partial ones (first block of a p, dim < 16), the left-over
+    // whole ones and fully-masked padding follow and go through the masking variant of the expansion.
+    static thread_local uint16_t host_items[256 * 18 + 32], partial[256 + 32];
+    uint32_t cnt = 0, npart = 0;
+    const uint32_t nblk = (dim + 15) / 16;
+    for (uint32_t p = 0; p + 1 < dim; ++p)
+        for (uint32_t qb = (p + 1) / 16; qb < nblk; ++qb) {
+            const bool whole = qb * 16 > p && qb * 16 + 16 <= dim;
+            if (whole) host_items[cnt++] = (uint16_t)((p << 8) | qb);
+            else partial[npart++] = (uint16_t)((p << 8) | qb);
+        }
+    const uint32_t full_rounds = cnt / (2 * KS);
+    for (uint32_t i = 0; i < npart; ++i) host_items[cnt++] = partial[i];
+    while (cnt == 0 || cnt % (2 * KS)) host_items[cnt++] = (uint16_t)(((dim - 1) << 8) | 0);   // fully masked padding
+    *n_full_rounds_out = full_rounds;
+    PO_HIP(hipMemcpyAsync(d_items, host_items, cnt * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    PO_HIP(hipStreamSynchronize(ctx->stream));                        // host_items is reused by the next call
+    *n_items_out = cnt;
+    return PO_OK;
+}
+
+int po_launch_kt_mfma_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint32_t n_items, uint32_t n_full_rounds,
+                            uint64_t* tiles) {
+    const uint8_t* rank8 = static_cast<const uint8_t*>(ws);
+    const uint16_t* d_items = reinterpret_cast<const uint16_t*>(static_cast<const uint8_t*>(ws) + ((a.npad * a.dim + 255) & ~(uint64_t)255));
+    const uint64_t nblocks = po_tile_count(a, TM);
+    if (tiles) *tiles += nblocks;
+    if (nblocks == 0) return PO_OK;
+    if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
+    const size_t shmem = ((256 * (a.dim + 16) + 15) & ~(size_t)15) + 2 * 256 * kSigStride + ((n_items * 2 + 15) & ~(size_t)15);
+    if (a.out_f32) {
+        auto k = kt_mfma_tile_kernel<float>;
+        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, rank8, d_items, n_items, n_full_rounds);
+    } else {
+        auto k = kt_mfma_tile_kernel<double>;
+        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, rank8, d_items, n_items, n_full_rounds);
+    }
+    PO_CHECK_LAUNCH("kt_mfma_tile_kernel");
+    return PO_OK;
+}

@@ -293,3 +293,23 @@ def test_jsd_general_kernel_near_duplicates(ctx):
     assert want[off & (want > 0)].min() < 1e-4                                     # the regime this test is about
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-14)
     assert abs(got[5, 40]) < 5e-14 and abs(got[17, 41]) < 5e-14      # accumulated rounding only
+
+
+def test_kt_mfma_and_valu_kernels_agree(ctx):
+    """Kendall tau through the int8-MFMA pair-sign kernel (default for D <= 256) and through the O(D^2) VALU
+    kernel (forced): identical integers S, so identical float64 results; both against the oracle."""
+    from oracle import phyloligo_oracle as po
+    contigs = _random_assembly(150, 61, lo=200, hi=4000) + [b"", b"ACGTACGTAC", b"A" * 50]
+    seq, offsets = pack(contigs)
+    for pattern in ("1111", "111", "11", "1"):
+        counts, totals = ctx.count_profiles(seq, offsets, pattern, "both")
+        fast, st = ctx.pairwise(counts, totals, "KT", want_stats=True)
+        slow, st2 = ctx.pairwise(counts, totals, "KT", want_stats=True, table_path=False)
+        assert st["kernel_id"] == 8 and st2["kernel_id"] == 5
+        assert np.array_equal(fast, slow)
+        assert np.array_equal(fast, fast.T)
+        if pattern in ("111", "11"):
+            oc, ot = po.compute_counts(contigs, pattern, "both")
+            want = po.pairwise_block(po.counts_to_frequencies(oc, ot), "KT")
+            np.testing.assert_allclose(fast, want, rtol=RTOL, atol=ATOL)
+        np.testing.assert_array_equal(ctx.pairwise(counts, totals, "KT", row_begin=3, row_end=140), fast[3:140])
