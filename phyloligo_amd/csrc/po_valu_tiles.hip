@@ -65,8 +65,9 @@ __device__ __forceinline__ void jsd_issue(const JsdConsts& C, double a, const do
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const double sum = a + b[e];
-        uint32_t toff;
-        asm("v_bfe_u32 %0, %1, 13, 7\n\tv_lshl_or_b32 %0, %0, 8, %2" : "=&v"(toff) : "v"(__double2hiint(sum)), "v"(C.tcopy));
+        // (hi >> 5) & 0x7F00 | tcopy: a VOP2 shift (2.4 cycles) + one VOP3 and-or (4.2) instead of two VOP3 ops
+        uint32_t toff = (uint32_t)__double2hiint(sum) >> 5;
+        asm("v_and_or_b32 %0, %0, %1, %2" : "+v"(toff) : "s"(0x7F00u), "v"(C.tcopy));
         psum[e] = sum;
         pte[e] = po_lds_read_d2(toff);
     }
@@ -75,6 +76,9 @@ __device__ __forceinline__ void jsd_issue(const JsdConsts& C, double a, const do
 // acc += s ln s with ln s = (eb ln2 + logc') + log1p(r), r = m invc - 1, log1p by a degree-4 Horner form.
 // 9 float64-rate + 5 integer instructions per pair and word (the inline asm pins the VOP3 forms hipcc
 // does not select by itself: v_and_or_b32, fma with the inline constant -1.0, fma with a VGPR constant).
+// Measured issue costs on gfx950 (tools/ubench/valu_rate.hip): float64 FMA/add 4.9 cycles per wave,
+// VOP3 integer ops (and_or, bfe, lshl_or, perm, med3, packed 16-bit) 4.3, plain VOP2 integer ops 2.4 --
+// so shifts are kept in VOP2 form and only fused where one VOP3 replaces two VOP2.
 __device__ __forceinline__ void jsd_eval(const JsdConsts& C, const double (&psum)[2], const double2 (&pte)[2], double* acc) {
     const double c3 = 1.0 / 3.0;
 #pragma unroll
@@ -85,7 +89,7 @@ __device__ __forceinline__ void jsd_eval(const JsdConsts& C, const double (&psum
         uint32_t mhi;
         asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(mhi) : "v"(hi), "s"(0x000FFFFFu), "v"(C.k3ff));
         const double m = __hiloint2double((int)mhi, __double2loint(sum));
-        const double ef = (double)__builtin_amdgcn_ubfe(hi, 20, 11);
+        const double ef = (double)(hi >> 20);                            // sum >= 0: no sign bit to strip (VOP2 shift)
         double r, q;
         asm("v_fma_f64 %0, %1, %2, -1.0" : "=v"(r) : "v"(m), "v"(te.x));
         asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "v"(r), "v"(C.c4), "s"(c3));
