@@ -24,6 +24,7 @@ constexpr int KC = 16;                            // words staged per step: 4 MF
 constexpr int kThreads = 256;
 constexpr int kRowStride = TM + TN + 16;          // +16 doubles: k-rows of one MFMA operand land in
 constexpr int kStageDoubles = KC * kRowStride;    // different bank halves (ds_read_b64, 32-lane groups)
+constexpr int kTrStride = 66;                     // transposed 16 x 64 block of a wave: lc*66 + lg hits 32 distinct bank pairs
 
 
 
@@ -139,28 +140,58 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
     }
 
     // ---- epilogue: lane holds rows lg + 4*reg, column lc of each 16 x 16 block -------------------
+    // The tile itself leaves as 128-byte row pieces (16 lanes x 8 B).  The mirrored tile is transposed
+    // through wave-private LDS (the staging buffers are free now), 16 columns at a time, so that it
+    // leaves as 512-byte row pieces of 16-byte stores instead of 32-byte crumbs.
     const bool mirror = po_tile_mirrors(A, ti, tj);
+    OUT* out = static_cast<OUT*>(A.out);
+    OUT* mir = static_cast<OUT*>(A.mirror);
+    const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
+    const uint64_t iw = i0 + wr * 64, jw = j0 + wc * 64;
+    double* wl = stage + wave * (16 * kTrStride);
+    const bool vec_mir = sizeof(OUT) == 8 && (A.ld_mirror & 1) == 0 && iw >= A.row_begin && ((iw - A.row_begin) & 1) == 0 &&
+                         (reinterpret_cast<uintptr_t>(A.mirror) & 15) == 0;
+    double ni[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) ni[m][reg] = norms[iw + m * 16 + lg + 4 * reg];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-        const uint64_t j = j0 + wc * 64 + n * 16 + lc;
-        if (j >= A.n) continue;
+        const uint64_t j = jw + n * 16 + lc;
         const double nj = norms[j];
+        const bool j_ok = j >= A.col_begin && j < n_cols;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const uint64_t i = i0 + wr * 64 + m * 16 + lg + 4 * reg;
-                if (!po_in_block(A, i, j)) continue;
+                const uint64_t i = iw + m * 16 + lg + 4 * reg;
                 const double g = acc[m][n][reg];
-                const double ni = norms[i];
                 double v;
                 if (METRIC == PO_EUCL) {
-                    v = sqrt(fmax((ni + nj) - 2.0 * g, 0.0));
+                    v = sqrt(fmax((ni[m][reg] + nj) - 2.0 * g, 0.0));
                     if (i == j) v = 0.0;
                 } else {  // PO_SC: 1 - Pearson correlation of the centred ranks; constant row -> NaN
-                    v = 1.0 - g / sqrt(ni * nj);
+                    v = 1.0 - g / sqrt(ni[m][reg] * nj);
                 }
-                po_store_pair<OUT>(A, i, j, v, mirror);
+                if (j_ok && i >= A.row_begin && i < n_rows) out[(i - A.row_begin) * A.ld_out + (j - A.col_begin)] = (OUT)v;
+                if (mirror) wl[lc * kTrStride + m * 16 + lg + 4 * reg] = v;
+            }
+        }
+        if (mirror) {                                      // wave-uniform; LDS operations of one wave execute in order
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const uint32_t jr = it * 2 + (lane >> 5), ic = 2 * (lane & 31);
+                const double2 w = *reinterpret_cast<const double2*>(wl + jr * kTrStride + ic);
+                const uint64_t jm = jw + n * 16 + jr, i = iw + ic;
+                if (jm < A.col_begin || jm >= n_cols) continue;
+                OUT* row = mir + (jm - A.col_begin) * A.ld_mirror;
+                if (vec_mir && i + 1 < n_rows) {
+                    *reinterpret_cast<double2*>(row + (i - A.row_begin)) = w;
+                } else {
+                    if (i >= A.row_begin && i < n_rows) row[i - A.row_begin] = (OUT)w.x;
+                    if (i + 1 >= A.row_begin && i + 1 < n_rows) row[i + 1 - A.row_begin] = (OUT)w.y;
+                }
             }
         }
     }
