@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
                 const double g = acc[m][n][reg];
                 double v;
                 if (METRIC == PO_EUCL) {
-                    v = sqrt(fmax((ni[m][reg] + nj) - 2.0 * g, 0.0));
+                    v = po_sqrt_nonneg(fmax((ni[m][reg] + nj) - 2.0 * g, 0.0));
                     if (i == j) v = 0.0;
                 } else {  // PO_SC: 1 - Pearson correlation of the centred ranks; constant row -> NaN
                     v = 1.0 - g / sqrt(ni[m][reg] * nj);

@@ -70,21 +70,6 @@ __global__ __launch_bounds__(256) void prep_i8_kernel(const uint32_t* __restrict
     }
 }
 
-// sqrt of a non-negative, normal-range float64: v_rsq_f64 seed (2^-23 accurate) + one coupled
-// Goldschmidt step + one residual correction -> within 1 ulp; exact 0 for 0 (no denormal scaling needed:
-// squared distances of frequency vectors are 0 or >= 1e-16).
-__device__ __forceinline__ double po_sqrt_nonneg(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    double h = 0.5 * y;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    const double d = fma(-g, g, x);
-    g = fma(d, h, g);
-    return x == 0.0 ? 0.0 : g;
-}
-
 // One orientation of a wave's 64 x 64 block: rows = records r0.., columns = records c0...  Values go to
 // dst[(row - row_off) * ld + (col - col_off)]; `swap` says that rows are the block's columns (mirror).
 template <typename OUT>

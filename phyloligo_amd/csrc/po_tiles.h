@@ -37,6 +37,21 @@ __device__ __forceinline__ double po_lds_read_f64(uint32_t) { return 0.0; }
 __device__ __forceinline__ void po_glds16(const void*, void*) {}
 #endif
 
+// sqrt of a non-negative, normal-range float64: v_rsq_f64 seed (2^-23 accurate) + one coupled
+// Goldschmidt step + one residual correction -> within 1 ulp; exact 0 for 0 (no denormal scaling needed:
+// squared distances of frequency vectors are 0 or >= 1e-16).
+__device__ __forceinline__ double po_sqrt_nonneg(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return x == 0.0 ? 0.0 : g;
+}
+
 // linear id -> tile of the upper triangle of a T x T tile grid (tj >= ti), row major
 __device__ __forceinline__ void po_tri_decode(uint64_t b, uint32_t T, uint32_t& ti, uint32_t& tj) {
     const double tt = 2.0 * T + 1.0;
