@@ -70,6 +70,14 @@ typedef enum po_dtype { PO_F64 = 0, PO_F32 = 1 } po_dtype;
                                    equal word totals, no exact int8-MFMA kernel for Eucl profiles <= 127,
                                    no packed-byte SAD kernel for BC, no int8-MFMA kernel for KT           */
 
+#define PO_FLAG_NO_RC_FOLD 4u /* JSD / BC: do not look for reverse-complement symmetric profiles.  By default
+                                 the input is checked on the device (count[w] == count[rc(w)] for every record
+                                 and word - what `-s both` with a palindromic pattern produces,
+                                 bin/phyloligo.py:141) and, if it holds, the sums over words run over one word
+                                 per {w, rc(w)} orbit: same result up to summation order, about half
+                                 the work.  The check reads one flag word back, i.e. it synchronises the
+                                 stream once per call; this flag avoids that.                             */
+
 /* Filled by po_pairwise* when non-NULL.  Times are HIP-event times on the context's stream;
  * asking for them makes the call synchronise. */
 typedef struct po_stats {
@@ -79,7 +87,7 @@ typedef struct po_stats {
     uint64_t pairs;        /* matrix entries written / 2 (unordered pairs incl. half the diagonal) */
     uint64_t tiles;        /* workgroup tiles launched                                            */
     uint32_t kernel_id;    /* which tile kernel ran (PO_KERNEL_*)                                 */
-    uint32_t reserved;
+    uint32_t rc_folded;    /* 1 if the reverse-complement folded operands were used (PO_FLAG_NO_RC_FOLD)  */
 } po_stats;
 
 #define PO_KERNEL_VALU_JSD 1u

@@ -19,12 +19,13 @@ PO_KL = 5          # Kount.py only (po_profile_distances)
 PO_F64, PO_F32 = 0, 1
 PO_FLAG_NO_SYMMETRY = 1
 PO_FLAG_NO_TABLE_PATH = 2
+PO_FLAG_NO_RC_FOLD = 4
 
 
 class PoStats(ctypes.Structure):
     _fields_ = [("prep_ms", ctypes.c_double), ("kernel_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
                 ("pairs", ctypes.c_uint64), ("tiles", ctypes.c_uint64), ("kernel_id", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32)]
+                ("rc_folded", ctypes.c_uint32)]
 
 
 class PoBlock(ctypes.Structure):

@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import (METRICS, STRANDS, PO_F32, PO_F64, PO_FLAG_NO_SYMMETRY, PO_FLAG_NO_TABLE_PATH, PoBlock, PoStats,
+from ._lib import (METRICS, STRANDS, PO_F32, PO_F64, PO_FLAG_NO_SYMMETRY, PO_FLAG_NO_TABLE_PATH, PO_FLAG_NO_RC_FOLD, PoBlock, PoStats,
                    check)
 
 
@@ -156,18 +156,21 @@ class Context:
         check(self._lib.po_pairwise_reserve(self._h, n, dim, METRICS[metric]))
 
     def pairwise(self, counts, totals, metric="Eucl", row_begin=0, row_end=None, dtype="float64", symmetric=True,
-                 out=None, want_stats=False, table_path=True):
+                 out=None, want_stats=False, table_path=True, rc_fold=True):
         """Rows [row_begin,row_end) x all columns of the distance matrix from integer profiles.
-        table_path=False forces the general JSD kernel even for record blocks with equal totals."""
+        table_path=False forces the general JSD kernel even for record blocks with equal totals;
+        rc_fold=False keeps every word even when the profiles are reverse-complement symmetric."""
         return self._pairwise(counts, totals, None, metric, row_begin, row_end, dtype, symmetric, out, want_stats,
-                              0 if table_path else PO_FLAG_NO_TABLE_PATH)
+                              (0 if table_path else PO_FLAG_NO_TABLE_PATH) | (0 if rc_fold else PO_FLAG_NO_RC_FOLD))
 
     def pairwise_freq(self, freq, metric="Eucl", row_begin=0, row_end=None, dtype="float64", symmetric=True,
-                      out=None, want_stats=False):
+                      out=None, want_stats=False, rc_fold=True):
         """The same from a float64 frequency matrix (the reference's `frequencies` argument)."""
-        return self._pairwise(None, None, freq, metric, row_begin, row_end, dtype, symmetric, out, want_stats)
+        return self._pairwise(None, None, freq, metric, row_begin, row_end, dtype, symmetric, out, want_stats,
+                              0 if rc_fold else PO_FLAG_NO_RC_FOLD)
 
-    def pairwise_blocks(self, counts, totals, metric, blocks, dtype="float64", want_stats=False, table_path=True):
+    def pairwise_blocks(self, counts, totals, metric, blocks, dtype="float64", want_stats=False, table_path=True,
+                        rc_fold=True):
         """Several rectangular blocks of one matrix in one call (device tensors only).  `blocks` is a
         list of dicts: rows=(lo,hi), cols=(lo,hi), out=<2-D tensor [rows, cols]>, optional
         mirror=<2-D tensor [cols, rows]>, optional triangular=True (rows == cols)."""
@@ -192,11 +195,13 @@ class Context:
         self._use_torch_stream()
         check(self._lib.po_pairwise_blocks_dev(self._h, counts.data_ptr(), totals.data_ptr(), n, dim, METRICS[metric],
                                                PO_F32 if f32 else PO_F64, arr, len(blocks),
-                                               0 if table_path else PO_FLAG_NO_TABLE_PATH,
+                                               (0 if table_path else PO_FLAG_NO_TABLE_PATH) |
+                                               (0 if rc_fold else PO_FLAG_NO_RC_FOLD),
                                                ctypes.byref(stats) if want_stats else None))
         if want_stats:
             return {"prep_ms": stats.prep_ms, "kernel_ms": stats.kernel_ms, "total_ms": stats.total_ms,
-                    "pairs": stats.pairs, "tiles": stats.tiles, "kernel_id": stats.kernel_id}
+                    "pairs": stats.pairs, "tiles": stats.tiles, "kernel_id": stats.kernel_id,
+                    "rc_folded": bool(stats.rc_folded)}
         return None
 
     def _pairwise(self, counts, totals, freq, metric, row_begin, row_end, dtype, symmetric, out, want_stats,
@@ -242,7 +247,8 @@ class Context:
                                             row_begin, row_end, code, _np_ptr(out), max(ld, n), flags, sp))
         if want_stats:
             return out, {"prep_ms": stats.prep_ms, "kernel_ms": stats.kernel_ms, "total_ms": stats.total_ms,
-                         "pairs": stats.pairs, "tiles": stats.tiles, "kernel_id": stats.kernel_id}
+                         "pairs": stats.pairs, "tiles": stats.tiles, "kernel_id": stats.kernel_id,
+                    "rc_folded": bool(stats.rc_folded)}
         return out
 
 

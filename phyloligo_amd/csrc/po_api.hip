@@ -84,6 +84,9 @@ extern "C" void po_ctx_destroy(po_ctx* ctx) {
     buf_free(&ctx->ws_aux);
     buf_free(&ctx->ws_io);
     buf_free(&ctx->ws_logtab);
+    buf_free(&ctx->ws_fold);
+    buf_free(&ctx->ws_fold_src);
+    if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     for (int i = 0; i < 4; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;
@@ -452,6 +455,20 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     double* rowstat = static_cast<double*>(ctx->ws_rowstat.p);
 
     if (stats) PO_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    // ---- strand-symmetric profiles: one word per reverse-complement orbit (JSD, BC; po_fold.hip) ----
+    uint32_t dbl_at = PO_NO_DOUBLING;
+    bool folded = false;
+    if ((metric == PO_JSD || metric == PO_BC) && !(flags & PO_FLAG_NO_RC_FOLD)) {
+        uint32_t dim_f = 0, at = PO_NO_DOUBLING;
+        rc = po_rc_fold(ctx, d_counts, d_freq, n, dim, metric == PO_BC ? 32u : 8u, &folded, &dim_f, &at);
+        if (rc) return rc;
+        if (folded) {
+            if (d_counts) d_counts = static_cast<const uint32_t*>(ctx->ws_fold.p);
+            else d_freq = static_cast<const double*>(ctx->ws_fold.p);
+            dim = dim_f;
+            dbl_at = at;
+        }
+    }
     // ---- prep: working layout + per-row terms (once) ----
     uint32_t* lessrank = nullptr;
     const unsigned long long* cls = nullptr;
@@ -469,7 +486,7 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         if (rc) return rc;
     }
     if (metric == PO_JSD || metric == PO_BC) {
-        rc = po_launch_rowstat(ctx, ft, n, dim, npad, rowstat, metric == PO_JSD ? ctx->ws_logtab.p : nullptr);
+        rc = po_launch_rowstat(ctx, ft, n, dim, npad, rowstat, metric == PO_JSD ? ctx->ws_logtab.p : nullptr, dbl_at);
     } else if (metric == PO_SC) {
         rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, ft, nullptr, rowstat);
     } else if (metric == PO_KT) {
@@ -520,6 +537,7 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         a.mirror = k.triangular ? k.out : k.mirror;
         a.ld_mirror = k.triangular ? k.ld_out : k.ld_mirror;
         a.out_f32 = (out_dtype == PO_F32);
+        a.dbl_at = dbl_at;
         static const bool dbg_no_mirror = getenv("PO_DEBUG_NO_MIRROR") != nullptr;   // timing experiments only
         if (dbg_no_mirror) a.mirror = nullptr;
         switch (metric) {
@@ -568,6 +586,7 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         stats->pairs = entries / 2;
         stats->tiles = tiles;
         stats->kernel_id = kid;
+        stats->rc_folded = folded ? 1u : 0u;
     }
     return PO_OK;
 }

@@ -93,9 +93,17 @@ __global__ __launch_bounds__(kThreads, 2) void bc_sad_tile_kernel(po_tile_args A
     gstage(0, 0);
     __syncthreads();
 
+    auto double_sums = [&]() {                                      // folded operands (po_fold.hip)
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[a][b] <<= 1;
+    };
+    const uint32_t dbl_group = A.dbl_at == PO_NO_DOUBLING ? PO_NO_DOUBLING : A.dbl_at / 4;   // a multiple of KC (gran 32)
     uint32_t cur = 0;
     for (uint32_t g0 = 0; g0 < groups_pad; g0 += KC) {
         if (g0 + KC < groups_pad) gstage(g0 + KC, cur ^ 1);
+        if (g0 == dbl_group) double_sums();
         const uint32_t* sA = stage + cur * kStageWords + ty * 8;
         const uint32_t* sB = stage + cur * kStageWords + KC * TM + tx * 2;
 #pragma unroll 4
@@ -117,6 +125,7 @@ __global__ __launch_bounds__(kThreads, 2) void bc_sad_tile_kernel(po_tile_args A
         __syncthreads();
         cur ^= 1;
     }
+    if (dbl_group != PO_NO_DOUBLING && dbl_group >= groups_pad) double_sums();
 
     // ---- epilogue: BC = (num / n) / (w_i + w_j) ------------------------------------------------------
     const double inv_n = 1.0 / (double)ntot;

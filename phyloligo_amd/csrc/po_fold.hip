@@ -1,0 +1,125 @@
+// Reverse-complement folding of strand-symmetric profiles (stage 2, JSD and Bray-Curtis).
+//
+// Under `-s both` the reference counts the words of  seq + revcomp(seq)  (select_strand,
+// /root/reference/phylopackage/bin/phyloligo.py:124-149, :141).  That string is its own reverse
+// complement, so whenever the pattern reads the same in both directions (every contiguous k-mer, `-k`; spaced
+// patterns such as 11011011) each window has a mirror window holding the reverse-complemented word, and
+//     count[w] == count[rc(w)]   exactly, for every record.
+// In the C,G,A,T digit coding of count2freq (:653) rc(w) = digits reversed, each XOR 1.  A metric that
+// is a sum over words of f(a_w, b_w) then only needs one word per orbit {w, rc(w)}:
+//     sum_w f(a_w, b_w) = 2 * sum_{w < rc(w)} f(a_w, b_w) + sum_{w == rc(w)} f(a_w, b_w),
+// i.e. 136 instead of 256 words at k=4 and 2080 instead of 4096 at k=6.  The property is CHECKED on the device for
+// the matrix at hand (one pass, fused with the fold itself) - it is a fact about the data, not a promise of
+// the caller - and the folded matrix is used only if every record has it.  Layout of a folded record:
+//     [ one representative per two-word orbit, ascending, zero padded to `gran` words | self-paired words, padded to 8 ]
+// The tile kernels walk it front to back and double their accumulators once, at word `dbl_at`
+// (po_tile_args), so the folded sums carry the same weights as the full ones.
+#include "po_internal.h"
+
+#include <vector>
+
+namespace {
+
+__device__ __host__ inline uint32_t rc_word(uint32_t w, uint32_t k) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        r = (r << 2) | ((w & 3u) ^ 1u);
+        w >>= 2;
+    }
+    return r;
+}
+
+// one wave per record: compare every word with its reverse complement, gather the folded record
+template <typename T>
+__global__ __launch_bounds__(256) void rc_fold_kernel(const T* __restrict__ in, uint64_t n, uint32_t dim, uint32_t k,
+                                                      const uint32_t* __restrict__ src, uint32_t dim_f,
+                                                      T* __restrict__ out, uint32_t* __restrict__ asym) {
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const T* x = in + row * dim;
+    bool sym = true;
+    for (uint32_t w = lane; w < dim; w += 64) sym = sym && (x[w] == x[rc_word(w, k)]);
+    if (!sym) *asym = 1u;                                   // benign race: every writer stores the same value
+    T* y = out + row * dim_f;
+    for (uint32_t d = lane; d < dim_f; d += 64) {
+        const uint32_t w = src[d];
+        y[d] = (w != 0xFFFFFFFFu) ? x[w] : (T)0;
+    }
+}
+
+}  // namespace
+
+// k with 4^k == dim, or 0
+static uint32_t log4_exact(uint32_t dim) {
+    uint32_t k = 0;
+    uint64_t d = 1;
+    while (d < dim) { d *= 4; ++k; }
+    return d == dim ? k : 0;
+}
+
+// Builds (or reuses) the source-word table for (dim, gran) and reports the folded width and doubling point.
+// *dim_f == 0: nothing to fold (dim is not a power of 4).
+static int fold_plan(po_ctx* ctx, uint32_t dim, uint32_t gran, uint32_t* dim_f, uint32_t* dbl_at) {
+    *dim_f = 0;
+    *dbl_at = 0xFFFFFFFFu;
+    const uint32_t k = log4_exact(dim);
+    if (k == 0 || k > PO_MAX_K) return PO_OK;
+    if (ctx->fold_dim == dim && ctx->fold_gran == gran) {
+        *dim_f = ctx->fold_dim_f;
+        *dbl_at = ctx->fold_dbl_at;
+        return PO_OK;
+    }
+    std::vector<uint32_t> pairs, selfs;
+    for (uint32_t w = 0; w < dim; ++w) {
+        const uint32_t r = rc_word(w, k);
+        if (w < r) pairs.push_back(w);
+        else if (w == r) selfs.push_back(w);
+    }
+    const uint32_t ppad = (uint32_t)po_round_up(pairs.size(), gran);
+    const uint32_t spad = (uint32_t)po_round_up(selfs.size(), 8);
+    std::vector<uint32_t> src(ppad + spad, 0xFFFFFFFFu);
+    for (size_t i = 0; i < pairs.size(); ++i) src[i] = pairs[i];
+    for (size_t i = 0; i < selfs.size(); ++i) src[ppad + i] = selfs[i];
+    int rc = po_buf_reserve(ctx, &ctx->ws_fold_src, src.size() * sizeof(uint32_t));
+    if (rc) return rc;
+    PO_HIP(hipMemcpyAsync(ctx->ws_fold_src.p, src.data(), src.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PO_HIP(hipStreamSynchronize(ctx->stream));              // src is a local vector
+    ctx->fold_dim = dim;
+    ctx->fold_gran = gran;
+    ctx->fold_dim_f = *dim_f = ppad + spad;
+    ctx->fold_dbl_at = *dbl_at = ppad;
+    return PO_OK;
+}
+
+// Folds counts (uint32) or frequencies (float64) into ctx->ws_fold if every record is reverse-complement
+// symmetric.  On return *folded tells whether ws_fold holds an [n][*dim_f] matrix to use instead of the input.
+// Costs one pass over the input and one 4-byte device-to-host read (the only host synchronisation of
+// the pairwise entry points; PO_FLAG_NO_RC_FOLD skips it).
+int po_rc_fold(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint64_t n, uint32_t dim, uint32_t gran,
+               bool* folded, uint32_t* dim_f, uint32_t* dbl_at) {
+    *folded = false;
+    int rc = fold_plan(ctx, dim, gran, dim_f, dbl_at);
+    if (rc || *dim_f == 0 || n == 0) return rc;
+    const size_t esz = d_counts ? sizeof(uint32_t) : sizeof(double);
+    rc = po_buf_reserve(ctx, &ctx->ws_fold, n * (uint64_t)*dim_f * esz + 256);
+    if (rc) return rc;
+    if (!ctx->h_flag) PO_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_flag), 64, hipHostMallocDefault));
+    uint8_t* base = static_cast<uint8_t*>(ctx->ws_fold.p);
+    uint32_t* asym = reinterpret_cast<uint32_t*>(base + po_round_up(n * (uint64_t)*dim_f * esz, 256));
+    PO_HIP(hipMemsetAsync(asym, 0, sizeof(uint32_t), ctx->stream));
+    const uint32_t k = log4_exact(dim);
+    const uint32_t* src = static_cast<const uint32_t*>(ctx->ws_fold_src.p);
+    const dim3 grid((uint32_t)((n + 3) / 4));
+    if (d_counts)
+        hipLaunchKernelGGL(rc_fold_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, d_counts, n, dim, k, src, *dim_f,
+                           reinterpret_cast<uint32_t*>(base), asym);
+    else
+        hipLaunchKernelGGL(rc_fold_kernel<double>, grid, dim3(256), 0, ctx->stream, d_freq, n, dim, k, src, *dim_f,
+                           reinterpret_cast<double*>(base), asym);
+    PO_CHECK_LAUNCH("rc_fold_kernel");
+    PO_HIP(hipMemcpyAsync(ctx->h_flag, asym, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PO_HIP(hipStreamSynchronize(ctx->stream));
+    *folded = (*ctx->h_flag == 0u);
+    return PO_OK;
+}

@@ -55,6 +55,10 @@ struct po_ctx {
     po_buf ws_io;                      // staging of the host-pointer entry points
     po_buf ws_logtab;                  // replicated log table of the JSD kernel
     bool logtab_ready = false;
+    po_buf ws_fold;                    // reverse-complement folded counts / frequencies (po_fold.hip) + flag word
+    po_buf ws_fold_src;                // source word of every folded column, for (fold_dim, fold_gran)
+    uint32_t fold_dim = 0, fold_gran = 0, fold_dim_f = 0, fold_dbl_at = 0;
+    uint32_t* h_flag = nullptr;        // pinned host word for the fold decision
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -98,7 +102,7 @@ int po_launch_freq_rowmajor(po_ctx* ctx, const uint32_t* d_counts, const uint64_
 // rowstat[0][n] = sum f ln f, rowstat[1][n] = sum f
 // logtab (may be NULL): the JSD log table; when given, rowstat[2] = sum f ln f by the tile kernel's table log
 int po_launch_rowstat(po_ctx* ctx, const double* d_ft, uint64_t n, uint32_t dim, uint64_t npad, double* d_rowstat,
-                      const void* logtab);
+                      const void* logtab, uint32_t dbl_at);
 
 // One rectangular block of the matrix handed to a tile kernel.
 struct po_tile_args {
@@ -114,7 +118,13 @@ struct po_tile_args {
     uint64_t ld_mirror;
     int out_f32;
     int triangular;         // rows == columns: only tiles on/above the diagonal are computed (mirror = out)
+    uint32_t dbl_at;        // word index at which running sums double (reverse-complement folded operands,
+                            // po_fold.hip); 0xFFFFFFFF = never.  A multiple of the kernel's staging step.
 };
+#define PO_NO_DOUBLING 0xFFFFFFFFu
+// Reverse-complement folding of strand-symmetric inputs (JSD, BC); see po_fold.hip
+int po_rc_fold(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint64_t n, uint32_t dim, uint32_t gran,
+               bool* folded, uint32_t* dim_f, uint32_t* dbl_at);
 // cls (may be NULL): per 128-record block, the common word total if the equal-total table path owns
 // the tiles of that class (po_jsd_lut.hip); valu_tile_kernel<JSD> skips tiles with equal non-zero classes.
 int po_launch_valu_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const unsigned long long* cls, uint64_t* tiles);

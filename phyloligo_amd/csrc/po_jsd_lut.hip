@@ -21,7 +21,6 @@ namespace {
 
 constexpr int TM = 128, TN = 128;
 constexpr int KC = 8;
-constexpr int kThreads = 256;
 constexpr int kLutEntries = 128;                       // sums 0..127  -> counts up to 63
 constexpr int kLutBytes = kLutEntries * 256;           // 32 copies x 8 B per entry
 constexpr int kStageWords = KC * (TM + TN);            // uint32 per buffer
@@ -123,9 +122,16 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void jsd_lut_tile_ker
     __syncthreads();
 
     const uint32_t tcopy = po_lds_addr(tab) + (lane & 31) * 8;
+    auto double_sums = [&]() {                                                   // folded operands (po_fold.hip)
+#pragma unroll
+        for (int a = 0; a < RPT; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[a][b] *= 2.0;
+    };
     uint32_t cur = 0;
     for (uint32_t k0 = 0; k0 < A.dim; k0 += KC) {
         if (k0 + KC < A.dim) gstage(k0 + KC, cur ^ 1);
+        if (k0 == A.dbl_at) double_sums();
         const uint32_t* sA = stage + cur * kStageWords + ty * RPT;
         const uint32_t* sB = stage + cur * kStageWords + KC * TM + tx * 2;
 #pragma unroll 2
@@ -159,6 +165,7 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void jsd_lut_tile_ker
         __syncthreads();
         cur ^= 1;
     }
+    if (A.dbl_at != PO_NO_DOUBLING && A.dbl_at >= A.dim) double_sums();
 
     // ---- epilogue: JSD = 1/2 (E_i + E_j - S) + ln 2,  S = Tsum/n - 2 ln n ----------------------------
     const double inv_n = 1.0 / (double)ntot;

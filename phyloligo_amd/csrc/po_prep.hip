@@ -63,16 +63,18 @@ __global__ __launch_bounds__(256) void freq_rowmajor_kernel(const uint32_t* __re
 // an empty record), rowstat[2][r] = sum_w f ln f again but with the SAME table logarithm, instruction for
 // instruction, that valu_tile_kernel<JSD> applies to a+b: its (tiny, systematic) errors then cancel in
 // 1/2 (E_a + E_b - S), and two identical records come out at rounding level instead of ~1e-13.
-// One lane per record, coalesced along n thanks to the transposed layout; fixed summation order.
+// One lane per record, coalesced along n thanks to the transposed layout; fixed summation order (with the
+// same doubling point as the tile kernels when the operands are reverse-complement folded, po_fold.hip).
 __global__ __launch_bounds__(256) void rowstat_kernel(const double* __restrict__ ft, uint64_t n, uint32_t dim,
                                                       uint64_t npad, double* __restrict__ rowstat,
-                                                      const double2* __restrict__ logtab) {
+                                                      const double2* __restrict__ logtab, uint32_t dbl_at) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= npad) return;
     const double LN2 = 0.693147180559945309417232121458;
     double e = 0.0, s = 0.0, et = 0.0;
     if (r < n) {
         for (uint32_t d = 0; d < dim; ++d) {
+            if (d == dbl_at) { e *= 2.0; s *= 2.0; et *= 2.0; }       // folded operands: two-word orbits end here
             const double f = ft[(uint64_t)d * npad + r];
             if (f > 0.0) {
                 e += f * log(f);
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(256) void rowstat_kernel(const double* __restrict__
             }
             s += f;
         }
+        if (dbl_at != PO_NO_DOUBLING && dbl_at >= dim) { e *= 2.0; s *= 2.0; et *= 2.0; }
     }
     rowstat[r] = e;
     rowstat[npad + r] = s;
@@ -127,9 +130,9 @@ int po_launch_freq_rowmajor(po_ctx* ctx, const uint32_t* d_counts, const uint64_
 }
 
 int po_launch_rowstat(po_ctx* ctx, const double* d_ft, uint64_t n, uint32_t dim, uint64_t npad, double* d_rowstat,
-                      const void* logtab) {
+                      const void* logtab, uint32_t dbl_at) {
     hipLaunchKernelGGL(rowstat_kernel, dim3((uint32_t)((npad + 255) / 256)), dim3(256), 0, ctx->stream, d_ft, n, dim,
-                       npad, d_rowstat, static_cast<const double2*>(logtab));
+                       npad, d_rowstat, static_cast<const double2*>(logtab), dbl_at);
     PO_CHECK_LAUNCH("rowstat_kernel");
     return PO_OK;
 }

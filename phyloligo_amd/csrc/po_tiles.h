@@ -82,7 +82,7 @@ __device__ __forceinline__ uint64_t po_xcd_swizzle(uint64_t b, uint64_t nb) {
 __device__ __forceinline__ void po_tri_band_decode(uint64_t L, uint32_t T, uint32_t& ti, uint32_t& tj) {
     const uint64_t S = kBand;
     // tiles in bands < r:  r*S(S+1)/2 + S*(r*T - S*r(r+1)/2)   (bands of S full rows; the last may be short)
-    auto before = [T, S](uint64_t r) { return r * (S * (S + 1) / 2) + S * (r * T - S * r * (r + 1) / 2); };
+    auto before = [T](uint64_t r) { const uint64_t S = kBand; return r * (S * (S + 1) / 2) + S * (r * T - S * r * (r + 1) / 2); };
     const uint64_t nbands = (T + S - 1) / S;
     // estimate by solving the quadratic, then fix up
     const double a = 0.5 * (double)(S * S), bq = (double)S * T + 0.5 * (double)S - 0.5 * (double)(S * S);

@@ -161,9 +161,16 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void valu_tile_kernel
         C.c4 = __hiloint2double((int)c4hi, (int)c4lo);                  // -1/4 held in a VGPR pair
     }
 
+    auto double_sums = [&]() {                                           // folded operands (po_fold.hip)
+#pragma unroll
+        for (int a = 0; a < RPT; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[a][b] *= 2.0;
+    };
     uint32_t cur = 0;
     for (uint32_t k0 = 0; k0 < A.dim; k0 += KC) {
         if (k0 + KC < A.dim) gstage(k0 + KC, cur ^ 1);
+        if (k0 == A.dbl_at) double_sums();
         const double* s = stage + cur * kStageDoubles;
 #pragma unroll 2
         for (int k = 0; k < KC; ++k) {
@@ -192,6 +199,7 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void valu_tile_kernel
         __syncthreads();      // also drains this wave's in-flight LDS-DMA (vmcnt) before the buffers swap
         cur ^= 1;
     }
+    if (A.dbl_at != PO_NO_DOUBLING && A.dbl_at >= A.dim) double_sums();
 
     // ---- epilogue -------------------------------------------------------------------------------
     // sum f ln f: for JSD the variant computed with this kernel's own table logarithm (errors cancel)

@@ -1,0 +1,150 @@
+"""Reverse-complement folding (csrc/po_fold.hip): `-s both` with a palindromic pattern gives
+count[w] == count[rc(w)]; JSD and BC then run over one word per orbit.  The folded result must agree with
+the unfolded one and with the oracle, the property must be detected from the data alone, and anything
+that lacks it must take the ordinary path."""
+import numpy as np
+import pytest
+
+from oracle import phyloligo_oracle as oracle
+from phyloligo_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-6, 1e-12
+# folded against unfolded: same mathematics, different summation order.  At D = 4096 the unfolded
+# sequential sum of 4096 terms of magnitude ~|ln f| carries ~1e-12 of rounding on its own (measured 8e-13).
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import phyloligo_amd as pa
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def contigs_ragged(n, seed, lo=300, hi=3000):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        length = int(rng.integers(lo, hi))
+        p = [(.2, .3, .3, .2), (.3, .2, .2, .3), (.25, .25, .25, .25), (.35, .15, .15, .35)][i % 4]
+        s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, size=length, p=p)].copy()
+        if i % 7 == 0:
+            s[length // 2] = ord("N")
+        out.append(s.tobytes())
+    out[5] = out[2]                      # a duplicate
+    out[9] = b"ACG"                      # shorter than the window: junction words only under `both`
+    out[11] = b"NNNNNNNN"                # empty profile
+    return out
+
+
+def pack(contigs):
+    seq = np.frombuffer(b"".join(contigs), dtype=np.uint8)
+    off = np.zeros(len(contigs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(c) for c in contigs])
+    return seq, off
+
+
+def rc_index(dim):
+    k = int(round(np.log(dim) / np.log(4)))
+    w = np.arange(dim)
+    r = np.zeros(dim, dtype=np.int64)
+    x = w.copy()
+    for _ in range(k):
+        r = (r << 2) | ((x & 3) ^ 1)
+        x >>= 2
+    return r
+
+
+@pytest.mark.parametrize("pattern", ["1", "11", "111", "1111", "11111", "11011", "101", "11011011"])
+@pytest.mark.parametrize("metric", ["JSD", "BC"])
+def test_both_strands_palindromic_pattern_folds(ctx, pattern, metric):
+    contigs = contigs_ragged(150, 77)
+    seq, off = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, off, pattern, "both")
+    assert np.array_equal(counts, counts[:, rc_index(counts.shape[1])])        # the symmetry the fold relies on
+    folded, st = ctx.pairwise(counts, totals, metric, want_stats=True)
+    plain, st0 = ctx.pairwise(counts, totals, metric, want_stats=True, rc_fold=False)
+    assert st["rc_folded"] and not st0["rc_folded"]
+    np.testing.assert_allclose(folded, plain, rtol=1e-9, atol=2e-11, equal_nan=True)
+    assert np.array_equal(np.isnan(folded), np.isnan(plain))
+    freq = oracle.counts_to_frequencies(counts.astype(np.int64), totals.astype(np.int64))
+    want = oracle.pairwise_distances(freq, metric)
+    np.testing.assert_allclose(folded, want, rtol=RTOL, atol=ATOL, equal_nan=True)
+    assert np.all(np.diag(folded) == 0.0)
+    if metric == "BC":
+        assert folded[2, 5] == 0.0 and folded[5, 2] == 0.0
+    else:
+        assert abs(folded[2, 5]) < 5e-14
+    # general kernels only (no table / SAD kernel), rows subset, float32 output, frequency input
+    general = ctx.pairwise(counts, totals, metric, table_path=False)
+    np.testing.assert_allclose(general, plain, rtol=1e-9, atol=2e-11, equal_nan=True)
+    sub = ctx.pairwise(counts, totals, metric, row_begin=17, row_end=93)
+    np.testing.assert_allclose(sub, plain[17:93], rtol=1e-9, atol=2e-11, equal_nan=True)
+    f32 = ctx.pairwise(counts, totals, metric, dtype="float32")
+    np.testing.assert_allclose(f32, plain.astype(np.float32), rtol=1e-6, atol=1e-7, equal_nan=True)
+    gf, stf = ctx.pairwise_freq(ctx.frequencies(counts, totals), metric, want_stats=True)
+    assert stf["rc_folded"]
+    np.testing.assert_allclose(gf, plain, rtol=1e-9, atol=2e-11, equal_nan=True)
+
+
+@pytest.mark.parametrize("metric", ["JSD", "BC"])
+def test_equal_totals_table_kernels_fold(ctx, metric):
+    """fixed-length contigs: the integer-sum table kernel (JSD) and the packed SAD kernel (BC) on folded operands"""
+    n = 400
+    seq, off = synthetic.contig_bytes(n, 2000, seed=4242)
+    for pattern in ("1111", "11011011"):
+        counts, totals = ctx.count_profiles(seq, off, pattern, "both")
+        folded, st = ctx.pairwise(counts, totals, metric, want_stats=True)
+        plain, st0 = ctx.pairwise(counts, totals, metric, want_stats=True, rc_fold=False)
+        assert st["rc_folded"] and st["kernel_id"] == st0["kernel_id"] and st["kernel_id"] in (6, 7)
+        np.testing.assert_allclose(folded, plain, rtol=1e-9, atol=2e-11)
+        freq = counts / totals[:, None].astype(np.float64)
+        rows = [0, 1, 57, 399]
+        want = oracle.pairwise_rows(freq, metric, rows)
+        np.testing.assert_allclose(folded[rows], want, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("strand,pattern", [("plus", "1111"), ("minus", "1111"), ("both", "1101"), ("both", "10011")])
+def test_asymmetric_profiles_are_not_folded(ctx, strand, pattern):
+    contigs = contigs_ragged(100, 5)
+    seq, off = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, off, pattern, strand)
+    for metric in ("JSD", "BC"):
+        got, st = ctx.pairwise(counts, totals, metric, want_stats=True)
+        assert not st["rc_folded"]
+        ref = ctx.pairwise(counts, totals, metric, rc_fold=False)
+        assert np.array_equal(got, ref, equal_nan=True)                  # the very same kernels ran
+
+
+def test_one_asymmetric_record_disables_folding(ctx):
+    contigs = contigs_ragged(130, 11)
+    seq, off = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, off, "1111", "both")
+    counts = counts.copy()
+    counts[129, 7] += 1                                                     # rc(7) != 7
+    totals = totals.copy()
+    totals[129] += 1
+    got, st = ctx.pairwise(counts, totals, "JSD", want_stats=True)
+    assert not st["rc_folded"]
+    freq = oracle.counts_to_frequencies(counts.astype(np.int64), totals.astype(np.int64))
+    np.testing.assert_allclose(got, oracle.pairwise_distances(freq, "JSD"), rtol=RTOL, atol=ATOL)
+
+
+def test_dimension_that_is_not_a_power_of_four(ctx):
+    rng = np.random.default_rng(3)
+    freq = rng.random((70, 50))
+    freq /= freq.sum(1, keepdims=True)
+    for metric in ("JSD", "BC"):
+        got, st = ctx.pairwise_freq(freq, metric, want_stats=True)
+        assert not st["rc_folded"]
+        np.testing.assert_allclose(got, oracle.pairwise_distances(freq, metric), rtol=RTOL, atol=ATOL)
+
+
+def test_other_metrics_ignore_the_fold(ctx):
+    contigs = contigs_ragged(90, 21)
+    seq, off = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, off, "1111", "both")
+    for metric in ("Eucl", "SC", "KT"):
+        _, st = ctx.pairwise(counts, totals, metric, want_stats=True)
+        assert not st["rc_folded"]
