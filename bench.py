@@ -138,6 +138,7 @@ def main():
             kms.append(st["kernel_ms"])
         kernel_ms = float(np.mean(kms))
         main_kernel_id = st["kernel_id"]
+        rc_folded = bool(st.get("rc_folded", False))
         rank_pairs = float(plan.pair_evaluations(rank))
         # compulsory HBM bytes per unordered pair = two mirrored float64 outputs + the
         # amortised one-time read of both profiles (uint32 counts)
@@ -165,6 +166,7 @@ def main():
                                    "float64 matrix resident in HBM" % (n, args.length, seed, args.pattern, args.metric),
                        "contigs": n, "dim": dim, "pairs": pairs, "sharding": plan.describe(),
                        "stage1_profile_ms": stage1_ms, "matrix_wall_ms": ms_per_step,
+                       "rc_folded": rc_folded,      # strand-symmetric profiles summed over one word per {w, rc(w)} orbit
                        "jsd_general_kernel_only": general},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_names.get(main_kernel_id, "tile kernel"),

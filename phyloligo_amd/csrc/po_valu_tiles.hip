@@ -16,11 +16,12 @@
 // E_x = sum x ln x and w_x = sum x (per row, po_prep.hip; w is 1 for a profile, 0 for an empty
 // record), S = sum s ln s with s = a + b.  It has exactly the reference's masking semantics (terms with a zero
 // numerator vanish, phylodist.py:22-24) and needs ONE logarithm per word and pair.  CDNA4 has
-// no float64 log instruction, so ln s is a 128-interval table reduction done in the ALU:
-//   s = 2^e m,  j = top 7 mantissa bits,  r = m*invc[j] - 1  (|r| <= 2^-8, one fma),
-//   ln s = (e*ln2 + logc[j]) + (r - r^2/2 + r^3/3 - r^4/4)          (abs. error < 1e-12)
-// The {invc, logc} pairs sit in LDS replicated 16x (one copy per bank quad) so that the
-// per-lane lookups of a wave never conflict.
+// no float64 log instruction, so ln s is a 512-interval table reduction done in the ALU:
+//   s = 2^e m,  j = top 9 mantissa bits,  r = m*invc[j] - 1  (|r| <= 2^-10, one fma),
+//   ln s = (e*ln2 + logc[j]) + (r - r^2/2 + r^3/3)                  (truncation < 2^-42 = 2.3e-13)
+// The {invc, logc} pairs sit in LDS replicated 8x (64 KiB; lanes tx and tx+8 of a 16-lane read group share
+// a copy, so a lookup costs 1.5 LDS passes on average - the LDS is far from busy in this kernel, the
+// vector ALU is not, and the finer table saves one float64 FMA per word and pair).
 #include "po_tiles.h"
 
 #include <math.h>
@@ -30,15 +31,16 @@ namespace {
 
 constexpr int TM = 128, TN = 128;     // tile of pairs per workgroup
 constexpr int KC = 8;                 // words staged per step
-constexpr int kTabEntries = 128;
-constexpr int kTabBytes = kTabEntries * 256;            // 16 copies x 16 B per entry
+constexpr int kTabEntries = 512;
+constexpr int kTabCopies = 8;
+constexpr int kTabBytes = kTabEntries * kTabCopies * 16;   // 64 KiB
 constexpr int kStageDoubles = KC * (TM + TN);           // one buffer
 constexpr double LN2 = 0.693147180559945309417232121458;
 
 struct JsdConsts {
     uint32_t tcopy;   // LDS byte address of this lane's table copy
     uint32_t k3ff;    // 0x3ff00000 in a VGPR (VOP3 takes no literal on gfx9)
-    double c4;        // -1/4 in a VGPR pair
+    double c3;        // 1/3 in a VGPR pair
 };
 
 // fragments of one staged word: RPT records of the row block (broadcast reads), 8 of the column block
@@ -59,28 +61,27 @@ __device__ __forceinline__ void load_frag(const double* s, int k, uint32_t tx, u
     }
 }
 
-// two pairs (a, b[0]) and (a, b[1]): sum, table address (7 top mantissa bits -> 256-byte row, this lane's
+// two pairs (a, b[0]) and (a, b[1]): sum, table address (9 top mantissa bits -> 128-byte row, this lane's
 // 16-byte copy), table read {invc, logc - 1023 ln2}
 __device__ __forceinline__ void jsd_issue(const JsdConsts& C, double a, const double* b, double (&psum)[2], double2 (&pte)[2]) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const double sum = a + b[e];
-        // (hi >> 5) & 0x7F00 | tcopy: a VOP2 shift (2.4 cycles) + one VOP3 and-or (4.2) instead of two VOP3 ops
-        uint32_t toff = (uint32_t)__double2hiint(sum) >> 5;
-        asm("v_and_or_b32 %0, %0, %1, %2" : "+v"(toff) : "s"(0x7F00u), "v"(C.tcopy));
+        // (hi >> 4) & 0xFF80 | tcopy: a VOP2 shift (2.4 cycles) + one VOP3 and-or (4.2) instead of two VOP3 ops
+        uint32_t toff = (uint32_t)__double2hiint(sum) >> 4;
+        asm("v_and_or_b32 %0, %0, %1, %2" : "+v"(toff) : "s"(0xFF80u), "v"(C.tcopy));
         psum[e] = sum;
         pte[e] = po_lds_read_d2(toff);
     }
 }
 
-// acc += s ln s with ln s = (eb ln2 + logc') + log1p(r), r = m invc - 1, log1p by a degree-4 Horner form.
-// 9 float64-rate + 5 integer instructions per pair and word (the inline asm pins the VOP3 forms hipcc
+// acc += s ln s with ln s = (eb ln2 + logc') + log1p(r), r = m invc - 1, log1p by a degree-3 Horner form.
+// 8 float64-rate + 4 integer instructions per pair and word (the inline asm pins the VOP3 forms hipcc
 // does not select by itself: v_and_or_b32, fma with the inline constant -1.0, fma with a VGPR constant).
 // Measured issue costs on gfx950 (tools/ubench/valu_rate.hip): float64 FMA/add 4.9 cycles per wave,
 // VOP3 integer ops (and_or, bfe, lshl_or, perm, med3, packed 16-bit) 4.3, plain VOP2 integer ops 2.4 --
 // so shifts are kept in VOP2 form and only fused where one VOP3 replaces two VOP2.
 __device__ __forceinline__ void jsd_eval(const JsdConsts& C, const double (&psum)[2], const double2 (&pte)[2], double* acc) {
-    const double c3 = 1.0 / 3.0;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const double sum = psum[e];
@@ -92,8 +93,7 @@ __device__ __forceinline__ void jsd_eval(const JsdConsts& C, const double (&psum
         const double ef = (double)(hi >> 20);                            // sum >= 0: no sign bit to strip (VOP2 shift)
         double r, q;
         asm("v_fma_f64 %0, %1, %2, -1.0" : "=v"(r) : "v"(m), "v"(te.x));
-        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "v"(r), "v"(C.c4), "s"(c3));
-        q = fma(r, q, -0.5);
+        asm("v_fma_f64 %0, %1, %2, -0.5" : "=v"(q) : "v"(r), "v"(C.c3));
         q = fma(r, q, 1.0);
         const double big = fma(ef, LN2, te.y);
         const double ln_s = fma(r, q, big);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void valu_tile_kernel
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
 
     if (METRIC == PO_JSD) {
-        const uint4* src = reinterpret_cast<const uint4*>(logtab);       // already replicated, 32 KiB
+        const uint4* src = reinterpret_cast<const uint4*>(logtab);       // already replicated, 64 KiB
         uint4* dst = reinterpret_cast<uint4*>(tab);
         for (uint32_t v = t; v < kTabBytes / 16; v += NT) dst[v] = src[v];
     }
@@ -152,13 +152,13 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void valu_tile_kernel
     __syncthreads();
 
     JsdConsts C;
-    C.tcopy = po_lds_addr(tab) + tx * 16;
+    C.tcopy = po_lds_addr(tab) + (tx & (kTabCopies - 1)) * 16;
     {
-        uint32_t c4lo, c4hi;
+        uint32_t c3lo, c3hi;
         asm volatile("v_mov_b32 %0, 0x3ff00000" : "=v"(C.k3ff));
-        asm volatile("v_mov_b32 %0, 0" : "=v"(c4lo));
-        asm volatile("v_mov_b32 %0, 0xbfd00000" : "=v"(c4hi));
-        C.c4 = __hiloint2double((int)c4hi, (int)c4lo);                  // -1/4 held in a VGPR pair
+        asm volatile("v_mov_b32 %0, 0x55555555" : "=v"(c3lo));
+        asm volatile("v_mov_b32 %0, 0x3fd55555" : "=v"(c3hi));
+        C.c3 = __hiloint2double((int)c3hi, (int)c3lo);                  // 1/3 held in a VGPR pair
     }
 
     auto double_sums = [&]() {                                           // folded operands (po_fold.hip)
@@ -256,22 +256,22 @@ int launch_metric(po_ctx* ctx, const po_tile_args& a, const unsigned long long* 
 
 }  // namespace
 
-// Log table for the 128 mantissa intervals [1 + j/128, 1 + (j+1)/128): {invc, -ln(invc) - 1023 ln2} with
-// invc = 1/midpoint, each entry replicated 16x so that copy c of entry j sits at byte j*256 + c*16
-// (banks 4c..4c+3): s = 2^(eb-1023) m, ln s = eb ln2 + (logc - 1023 ln2) + log1p(m invc - 1).
+// Log table for the 512 mantissa intervals [1 + j/512, 1 + (j+1)/512): {invc, -ln(invc) - 1023 ln2} with
+// invc = 1/midpoint, each entry replicated 8x so that copy c of entry j sits at byte j*128 + c*16:
+// s = 2^(eb-1023) m, ln s = eb ln2 + (logc - 1023 ln2) + log1p(m invc - 1).
 int po_logtab_init(po_ctx* ctx) {
     if (ctx->logtab_ready) return PO_OK;
     int rc = po_buf_reserve(ctx, &ctx->ws_logtab, kTabBytes);
     if (rc) return rc;
-    static double host_tab[kTabEntries * 16 * 2];
+    static double host_tab[kTabEntries * kTabCopies * 2];
     const long double ln2 = 0.693147180559945309417232121458176568L;
     for (int j = 0; j < kTabEntries; ++j) {
         const double c = 1.0 + (j + 0.5) / kTabEntries;
         const double invc = 1.0 / c;
         const long double logc = -logl((long double)invc);
-        for (int r = 0; r < 16; ++r) {
-            host_tab[(j * 16 + r) * 2 + 0] = invc;
-            host_tab[(j * 16 + r) * 2 + 1] = (double)(logc - 1023.0L * ln2);
+        for (int r = 0; r < kTabCopies; ++r) {
+            host_tab[(j * kTabCopies + r) * 2 + 0] = invc;
+            host_tab[(j * kTabCopies + r) * 2 + 1] = (double)(logc - 1023.0L * ln2);
         }
     }
     PO_HIP(hipMemcpyAsync(ctx->ws_logtab.p, host_tab, kTabBytes, hipMemcpyHostToDevice, ctx->stream));
