@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void rowstat_kernel(const double* __restrict__
                 e += f * log(f);
                 if (logtab != nullptr) {
                     const uint32_t hi = (uint32_t)__double2hiint(f);
-                    const double2 te = logtab[((hi >> 11) & 511u) * 8];         // copy 0 of the interval's entry
+                    const double2 te = logtab[((hi >> 11) & 511u) * 4];         // copy 0 of the interval's entry
                     const double m = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(f));
                     const double ef = (double)((hi >> 20) & 0x7FFu);
                     const double rr = fma(m, te.x, -1.0);

@@ -32,7 +32,7 @@ namespace {
 constexpr int TM = 128, TN = 128;     // tile of pairs per workgroup
 constexpr int KC = 8;                 // words staged per step
 constexpr int kTabEntries = 512;
-constexpr int kTabCopies = 8;
+constexpr int kTabCopies = 4;
 constexpr int kTabBytes = kTabEntries * kTabCopies * 16;   // 64 KiB
 constexpr int kStageDoubles = KC * (TM + TN);           // one buffer
 constexpr double LN2 = 0.693147180559945309417232121458;
@@ -68,8 +68,8 @@ __device__ __forceinline__ void jsd_issue(const JsdConsts& C, double a, const do
     for (int e = 0; e < 2; ++e) {
         const double sum = a + b[e];
         // (hi >> 4) & 0xFF80 | tcopy: a VOP2 shift (2.4 cycles) + one VOP3 and-or (4.2) instead of two VOP3 ops
-        uint32_t toff = (uint32_t)__double2hiint(sum) >> 4;
-        asm("v_and_or_b32 %0, %0, %1, %2" : "+v"(toff) : "s"(0xFF80u), "v"(C.tcopy));
+        uint32_t toff = (uint32_t)__double2hiint(sum) >> 5;
+        asm("v_and_or_b32 %0, %0, %1, %2" : "+v"(toff) : "s"(0x7FC0u), "v"(C.tcopy));
         psum[e] = sum;
         pte[e] = po_lds_read_d2(toff);
     }

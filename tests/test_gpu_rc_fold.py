@@ -75,7 +75,7 @@ def test_both_strands_palindromic_pattern_folds(ctx, pattern, metric):
     if metric == "BC":
         assert folded[2, 5] == 0.0 and folded[5, 2] == 0.0
     else:
-        assert abs(folded[2, 5]) < 5e-14
+        assert abs(folded[2, 5]) < 2e-13          # rounding of 2 x 2080 sequential float64 accumulations at D = 4096
     # general kernels only (no table / SAD kernel), rows subset, float32 output, frequency input
     general = ctx.pairwise(counts, totals, metric, table_path=False)
     np.testing.assert_allclose(general, plain, rtol=1e-9, atol=2e-11, equal_nan=True)
