@@ -29,23 +29,72 @@ __device__ __host__ inline uint32_t rc_word(uint32_t w, uint32_t k) {
     return r;
 }
 
-// one wave per record: compare every word with its reverse complement, gather the folded record
+// A workgroup stages `rpb` whole records in LDS with coalesced loads (records are contiguous in memory), then
+// every lane takes folded columns: the representative word and its reverse complement are compared (both
+// reads hit LDS, so the scattered partner costs nothing in HBM) and the representative is written out.
 template <typename T>
 __global__ __launch_bounds__(256) void rc_fold_kernel(const T* __restrict__ in, uint64_t n, uint32_t dim, uint32_t k,
-                                                      const uint32_t* __restrict__ src, uint32_t dim_f,
+                                                      const uint32_t* __restrict__ src, uint32_t dim_f, uint32_t rpb,
                                                       T* __restrict__ out, uint32_t* __restrict__ asym) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    T* rec = reinterpret_cast<T*>(smem);
+    const uint64_t row0 = (uint64_t)blockIdx.x * rpb;
+    const uint32_t rows = (uint32_t)min((uint64_t)rpb, n - row0);
+    const T* x = in + row0 * dim;
+    for (uint32_t e = threadIdx.x; e < rows * dim; e += 256) rec[e] = x[e];
+    __syncthreads();
+    bool sym = true;
+    T* y = out + row0 * dim_f;
+    for (uint32_t e = threadIdx.x; e < rows * dim_f; e += 256) {
+        const uint32_t r = e / dim_f, d = e - r * dim_f;
+        const uint32_t w = src[d];
+        T v = (T)0;
+        if (w != 0xFFFFFFFFu) {
+            v = rec[r * dim + w];
+            sym = sym && (v == rec[r * dim + rc_word(w, k)]);
+        }
+        y[e] = v;
+    }
+    if (!sym) *asym = 1u;                                   // benign race: every writer stores the same value
+}
+
+// rows too long for LDS (dim > 8192 words): one wave per record, partner reads from global memory
+template <typename T>
+__global__ __launch_bounds__(256) void rc_fold_long_kernel(const T* __restrict__ in, uint64_t n, uint32_t dim, uint32_t k,
+                                                           const uint32_t* __restrict__ src, uint32_t dim_f,
+                                                           T* __restrict__ out, uint32_t* __restrict__ asym) {
     const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     if (row >= n) return;
     const T* x = in + row * dim;
-    bool sym = true;
-    for (uint32_t w = lane; w < dim; w += 64) sym = sym && (x[w] == x[rc_word(w, k)]);
-    if (!sym) *asym = 1u;                                   // benign race: every writer stores the same value
     T* y = out + row * dim_f;
+    bool sym = true;
     for (uint32_t d = lane; d < dim_f; d += 64) {
         const uint32_t w = src[d];
-        y[d] = (w != 0xFFFFFFFFu) ? x[w] : (T)0;
+        T v = (T)0;
+        if (w != 0xFFFFFFFFu) {
+            v = x[w];
+            sym = sym && (v == x[rc_word(w, k)]);
+        }
+        y[d] = v;
     }
+    if (!sym) *asym = 1u;
+}
+
+template <typename T>
+int launch_fold(po_ctx* ctx, const T* in, uint64_t n, uint32_t dim, uint32_t k, const uint32_t* src, uint32_t dim_f,
+                T* out, uint32_t* asym) {
+    const size_t row_bytes = (size_t)dim * sizeof(T);
+    if (row_bytes <= 32768) {
+        const uint32_t rpb = (uint32_t)(32768 / row_bytes > 16 ? 16 : 32768 / row_bytes);
+        hipLaunchKernelGGL(rc_fold_kernel<T>, dim3((uint32_t)((n + rpb - 1) / rpb)), dim3(256), rpb * row_bytes, ctx->stream,
+                           in, n, dim, k, src, dim_f, rpb, out, asym);
+    } else {
+        hipLaunchKernelGGL(rc_fold_long_kernel<T>, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, ctx->stream, in, n, dim, k,
+                           src, dim_f, out, asym);
+    }
+    PO_CHECK_LAUNCH("rc_fold_kernel");
+    return PO_OK;
 }
 
 }  // namespace
@@ -110,14 +159,9 @@ int po_rc_fold(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint
     PO_HIP(hipMemsetAsync(asym, 0, sizeof(uint32_t), ctx->stream));
     const uint32_t k = log4_exact(dim);
     const uint32_t* src = static_cast<const uint32_t*>(ctx->ws_fold_src.p);
-    const dim3 grid((uint32_t)((n + 3) / 4));
-    if (d_counts)
-        hipLaunchKernelGGL(rc_fold_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, d_counts, n, dim, k, src, *dim_f,
-                           reinterpret_cast<uint32_t*>(base), asym);
-    else
-        hipLaunchKernelGGL(rc_fold_kernel<double>, grid, dim3(256), 0, ctx->stream, d_freq, n, dim, k, src, *dim_f,
-                           reinterpret_cast<double*>(base), asym);
-    PO_CHECK_LAUNCH("rc_fold_kernel");
+    rc = d_counts ? launch_fold<uint32_t>(ctx, d_counts, n, dim, k, src, *dim_f, reinterpret_cast<uint32_t*>(base), asym)
+                  : launch_fold<double>(ctx, d_freq, n, dim, k, src, *dim_f, reinterpret_cast<double*>(base), asym);
+    if (rc) return rc;
     PO_HIP(hipMemcpyAsync(ctx->h_flag, asym, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     PO_HIP(hipStreamSynchronize(ctx->stream));
     *folded = (*ctx->h_flag == 0u);

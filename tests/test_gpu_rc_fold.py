@@ -148,3 +148,18 @@ def test_other_metrics_ignore_the_fold(ctx):
     for metric in ("Eucl", "SC", "KT"):
         _, st = ctx.pairwise(counts, totals, metric, want_stats=True)
         assert not st["rc_folded"]
+
+
+def test_long_rows_fold_without_lds_staging(ctx):
+    """k = 8: a 65 536-word record does not fit the fold kernel's LDS staging (rc_fold_long_kernel)"""
+    contigs = contigs_ragged(24, 9, lo=2000, hi=6000)
+    seq, off = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, off, "11111111", "both")
+    assert counts.shape[1] == 65536
+    for metric in ("JSD", "BC"):
+        folded, st = ctx.pairwise(counts, totals, metric, want_stats=True)
+        plain = ctx.pairwise(counts, totals, metric, rc_fold=False)
+        assert st["rc_folded"]
+        np.testing.assert_allclose(folded, plain, rtol=1e-9, atol=2e-11, equal_nan=True)
+        freq = oracle.counts_to_frequencies(counts.astype(np.int64), totals.astype(np.int64))
+        np.testing.assert_allclose(folded, oracle.pairwise_block(freq, metric), rtol=RTOL, atol=ATOL, equal_nan=True)
