@@ -395,7 +395,7 @@ static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
         rc = po_buf_reserve(ctx, &ctx->ws_aux, po_jsd_lut_workspace(n, dim));
         if (rc) return rc;
     }
-    if (metric == PO_EUCL) {
+    if (metric == PO_EUCL || (metric == PO_SC && po_gram_i8_sc_supported(dim))) {
         rc = po_buf_reserve(ctx, &ctx->ws_aux, po_gram_i8_workspace(n, dim));
         if (rc) return rc;
     }
@@ -477,21 +477,29 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         // profiles that fit int8 go through the exact integer MFMA kernel; both tile kernels are launched
         // and the device-side flag decides which one does the work (and whether the float64 operand
         // matrix is built at all)
-        rc = po_launch_gram_i8_prep(ctx, d_counts, d_totals, n, dim, npad, ctx->ws_aux.p, &i8flag);
+        rc = po_launch_gram_i8_prep(ctx, d_counts, d_totals, false, n, dim, npad, ctx->ws_aux.p, &i8flag);
         if (rc) return rc;
     }
+    const uint32_t i8_upto = po_gram_i8_value_limit(dim);
+    // Spearman: the doubled centred ranks are small integers -> the same exact int8 kernel (two digit planes)
+    const bool sc_i8 = metric == PO_SC && po_gram_i8_sc_supported(dim) && !(flags & PO_FLAG_NO_TABLE_PATH);
     if (metric == PO_EUCL || metric == PO_JSD || metric == PO_BC) {
         rc = d_freq ? po_launch_prep_freq(ctx, d_freq, n, dim, npad, ft)
-                    : po_launch_prep(ctx, d_counts, d_totals, n, dim, npad, ft, i8flag);
+                    : po_launch_prep(ctx, d_counts, d_totals, n, dim, npad, ft, i8flag, i8_upto);
         if (rc) return rc;
     }
     if (metric == PO_JSD || metric == PO_BC) {
         rc = po_launch_rowstat(ctx, ft, n, dim, npad, rowstat, metric == PO_JSD ? ctx->ws_logtab.p : nullptr, dbl_at);
+    } else if (sc_i8) {
+        int32_t* r2 = static_cast<int32_t*>(ctx->ws_freq.p);           // the float64 operand buffer is free on this path
+        rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, nullptr, nullptr, r2, rowstat);
+        if (rc) return rc;
+        rc = po_launch_gram_i8_prep(ctx, reinterpret_cast<const uint32_t*>(r2), nullptr, true, n, dim, npad, ctx->ws_aux.p, nullptr);
     } else if (metric == PO_SC) {
-        rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, ft, nullptr, rowstat);
+        rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, ft, nullptr, nullptr, rowstat);
     } else if (metric == PO_KT) {
         lessrank = static_cast<uint32_t*>(ctx->ws_aux.p);
-        rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, nullptr, lessrank, rowstat);
+        rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, nullptr, lessrank, nullptr, rowstat);
     }
     if (rc) return rc;
     uint32_t kt_items = 0, kt_full_rounds = 0;
@@ -500,8 +508,8 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         rc = po_launch_kt_mfma_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, &kt_items, &kt_full_rounds);
         if (rc) return rc;
     }
-    if (metric == PO_EUCL || metric == PO_SC) {
-        rc = po_launch_gram_norms(ctx, ft, dim, npad, rowstat, i8flag);
+    if (metric == PO_EUCL || (metric == PO_SC && !sc_i8)) {
+        rc = po_launch_gram_norms(ctx, ft, dim, npad, rowstat, i8flag, i8_upto);
         if (rc) return rc;
     }
     if (metric == PO_JSD && d_counts && !(flags & PO_FLAG_NO_TABLE_PATH)) {
@@ -559,13 +567,16 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
                 break;
             case PO_EUCL:
                 if (i8flag) {
-                    rc = po_launch_gram_i8_tiles(ctx, a, ctx->ws_aux.p, &tiles);
+                    rc = po_launch_gram_i8_tiles(ctx, PO_EUCL, a, ctx->ws_aux.p, &tiles);
                     if (rc) return rc;
                 }
-                rc = po_launch_gram_f64(ctx, PO_EUCL, a, i8flag, i8flag ? nullptr : &tiles);
+                rc = po_launch_gram_f64(ctx, PO_EUCL, a, i8flag, i8_upto, i8flag ? nullptr : &tiles);
                 kid = i8flag ? PO_KERNEL_MFMA_I8_GRAM : PO_KERNEL_MFMA_F64_GRAM;
                 break;
-            case PO_SC: rc = po_launch_gram_f64(ctx, PO_SC, a, nullptr, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; break;
+            case PO_SC:
+                if (sc_i8) { rc = po_launch_gram_i8_tiles(ctx, PO_SC, a, ctx->ws_aux.p, &tiles); kid = PO_KERNEL_MFMA_I8_GRAM; }
+                else { rc = po_launch_gram_f64(ctx, PO_SC, a, nullptr, 0, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; }
+                break;
             case PO_KT:
                 if (kt_mfma) { rc = po_launch_kt_mfma_tiles(ctx, a, ctx->ws_freq.p, kt_items, kt_full_rounds, &tiles); kid = PO_KERNEL_MFMA_I8_KT; }
                 else { rc = po_launch_kt(ctx, lessrank, n, dim, a, &tiles); kid = PO_KERNEL_VALU_KT; }

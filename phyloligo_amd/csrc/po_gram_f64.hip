@@ -31,8 +31,9 @@ constexpr int kTrStride = 66;                     // transposed 16 x 64 block of
 
 // |x_r|^2 for 16 records per wave, by the same k-ascending MFMA chain the tile kernel uses.
 __global__ __launch_bounds__(64) void gram_diag_kernel(const double* __restrict__ xt, uint32_t dim, uint64_t npad,
-                                                       double* __restrict__ norms, const uint32_t* __restrict__ skip_if_le127) {
-    if (skip_if_le127 != nullptr && *skip_if_le127 <= 127u) return;
+                                                       double* __restrict__ norms, const uint32_t* __restrict__ skip_flag,
+                                                       uint32_t skip_upto) {
+    if (skip_flag != nullptr && *skip_flag <= skip_upto) return;
     const uint32_t l = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * 16;
     const uint32_t c = l & 15, g = l >> 4;
@@ -52,8 +53,8 @@ __global__ __launch_bounds__(64) void gram_diag_kernel(const double* __restrict_
 
 template <int METRIC, typename OUT>
 __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, const double* __restrict__ norms,
-                                                                const uint32_t* __restrict__ i8flag) {
-    if (i8flag != nullptr && *i8flag <= 127u) return;      // exact int8 kernel owns the matrix (po_gram_i8.hip)
+                                                                const uint32_t* __restrict__ i8flag, uint32_t i8_upto) {
+    if (i8flag != nullptr && *i8flag <= i8_upto) return;   // an exact int8 kernel owns the matrix (po_gram_i8.hip)
     extern __shared__ __align__(16) unsigned char smem[];
     double* stage = reinterpret_cast<double*>(smem);                    // [2][KC][kRowStride]
 
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
 }
 
 template <int METRIC>
-int launch_gram(po_ctx* ctx, const po_tile_args& a, const double* norms, const uint32_t* i8flag, uint64_t* tiles) {
+int launch_gram(po_ctx* ctx, const po_tile_args& a, const double* norms, const uint32_t* i8flag, uint32_t i8_upto, uint64_t* tiles) {
     const uint64_t nblocks = po_tile_count(a, TM);
     if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
@@ -207,9 +208,9 @@ int launch_gram(po_ctx* ctx, const po_tile_args& a, const double* norms, const u
     PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tile_kernel<METRIC, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tile_kernel<METRIC, double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     if (a.out_f32)
-        hipLaunchKernelGGL((gram_tile_kernel<METRIC, float>), dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, norms, i8flag);
+        hipLaunchKernelGGL((gram_tile_kernel<METRIC, float>), dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, norms, i8flag, i8_upto);
     else
-        hipLaunchKernelGGL((gram_tile_kernel<METRIC, double>), dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, norms, i8flag);
+        hipLaunchKernelGGL((gram_tile_kernel<METRIC, double>), dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, norms, i8flag, i8_upto);
     PO_CHECK_LAUNCH("gram_tile_kernel");
     return PO_OK;
 }
@@ -217,17 +218,18 @@ int launch_gram(po_ctx* ctx, const po_tile_args& a, const double* norms, const u
 }  // namespace
 
 // squared norms of every operand row into rowstat[2][npad] (once per problem, before the tile launches)
-int po_launch_gram_norms(po_ctx* ctx, const double* ft, uint32_t dim, uint64_t npad, double* rowstat, const uint32_t* skip_if_le127) {
-    hipLaunchKernelGGL(gram_diag_kernel, dim3((uint32_t)(npad / 16)), dim3(64), 0, ctx->stream, ft, dim, npad, rowstat + 2 * npad, skip_if_le127);
+int po_launch_gram_norms(po_ctx* ctx, const double* ft, uint32_t dim, uint64_t npad, double* rowstat, const uint32_t* skip_flag,
+                         uint32_t skip_upto) {
+    hipLaunchKernelGGL(gram_diag_kernel, dim3((uint32_t)(npad / 16)), dim3(64), 0, ctx->stream, ft, dim, npad, rowstat + 2 * npad, skip_flag, skip_upto);
     PO_CHECK_LAUNCH("gram_diag_kernel");
     return PO_OK;
 }
 
 // a.ft is the operand matrix (frequencies for Eucl, centred ranks for SC)
-int po_launch_gram_f64(po_ctx* ctx, int metric, const po_tile_args& a, const uint32_t* i8flag, uint64_t* tiles) {
+int po_launch_gram_f64(po_ctx* ctx, int metric, const po_tile_args& a, const uint32_t* i8flag, uint32_t i8_upto, uint64_t* tiles) {
     const double* norms = a.rowstat + 2 * a.npad;
-    if (metric == PO_EUCL) return launch_gram<PO_EUCL>(ctx, a, norms, i8flag, tiles);
-    if (metric == PO_SC) return launch_gram<PO_SC>(ctx, a, norms, nullptr, tiles);
+    if (metric == PO_EUCL) return launch_gram<PO_EUCL>(ctx, a, norms, i8flag, i8_upto, tiles);
+    if (metric == PO_SC) return launch_gram<PO_SC>(ctx, a, norms, nullptr, 0, tiles);
     po_set_error("po_launch_gram_f64: metric %d is not a Gram-form metric", metric);
     return PO_EINVAL;
 }

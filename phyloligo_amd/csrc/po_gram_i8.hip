@@ -1,18 +1,26 @@
-// Stage 2, Euclidean distance from EXACT integer dot products on the int8 matrix cores.
+// Stage 2, Gram-form metrics from EXACT integer dot products on the int8 matrix cores:
+// Euclidean distance of count profiles and Spearman's rank correlation.
 //
-// Same quantity as gram_tile_kernel<Eucl> (phylodist.Eucl,
-// /root/reference/phylopackage/core/phylodist.py:36-41):
-//     |a-b|^2 = S_a/n_a^2 + S_b/n_b^2 - 2 G/(n_a n_b),   S_x = sum c_x^2,   G = sum c_a c_b
-// When no count exceeds 127 (every 2 kb contig at k=4; max 38 measured) the profiles fit int8 and
-// v_mfma_i32_32x32x32_i8 gives G exactly, at ~60x the float64 MFMA rate: the matrix-core time becomes
-// negligible and the kernel is bound by writing the 16 B per pair of output.  Because the MFMA work is
-// nearly free, the transposed tile is produced by a second MFMA with the operands swapped (G^T = B A^T)
-// instead of a transposing store: both the tile and its mirror are written as full 256-byte row
-// segments straight from the accumulator layout (lanes 0..31 = 32 consecutive columns).
+// Same quantities as gram_tile_kernel<Eucl|SC> (po_gram_f64.hip):
+//   phylodist.Eucl (/root/reference/phylopackage/core/phylodist.py:36-41)
+//     |a-b|^2 = S_a/n_a^2 + S_b/n_b^2 - 2 G/(n_a n_b),   S_x = sum c_x^2,   G = sum c_a c_b   (integer counts c)
+//   phylodist.SC (:82-85, as intended: 1 - spearmanr)
+//     1 - G / sqrt(N_a N_b),  G = sum r_a r_b,  N_x = sum r_x^2,  r = 2 * centred average rank = 2 #less + #equal - D
+// Both G are sums of products of small integers.  A value v is split into 7-bit digits v = 128 hi + lo
+// (lo in 0..127, hi signed), each digit plane is an int8 matrix, and
+//     G = 16384 <hi_a,hi_b> + 128 (<hi_a,lo_b> + <lo_a,hi_b>) + <lo_a,lo_b>
+// comes EXACTLY out of v_mfma_i32_32x32x32_i8 (int32 accumulators, combined in float64 below 2^53).
+// One plane covers counts <= 127 (every 2 kb contig at k=4: max 38 measured), two planes cover |v| <= 16383
+// (contigs up to ~1 Mb at k=4; ranks for any D <= 8191).  The int8 MFMA rate is ~60x the float64 one, so the
+// matrix-core time is small and the kernel is bound by its epilogue and by writing 16 B per pair.
 //
-// Operands come straight from the L2 / Infinity-Cache resident int8 matrix (12.8 MB at N=50k, D=256);
-// no LDS staging is needed.  Eligibility (max count <= 127) is decided on the device: this kernel exits
-// when the flag is clear, gram_tile_kernel<Eucl> exits when it is set (po_gram_f64.hip).
+// Operand layout (built per call by prep_planes_kernel): plane[p][k/16][record][k%16] - 16-byte K-chunks
+// of 128 consecutive records are contiguous (2 KiB), so a tile's operands are staged by LDS-DMA with fully
+// coalesced 1 KiB instructions and the MFMA operand reads (16 B per lane, consecutive records) are
+// conflict free.  The order of K inside the dot product is irrelevant as long as both operands agree.
+//
+// Eligibility is decided on the device from the largest |value| of the matrix: every candidate kernel is
+// launched and all but one exit at once (no host synchronisation); see po_api.hip.
 #include "po_tiles.h"
 
 namespace {
@@ -21,173 +29,274 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int TM = 128, TN = 128;
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;                       // 8 waves: 4 x 2 blocks of 32 x 64 pairs
+constexpr int KCH = 128;                            // bytes of K per record and staging step = 4 MFMA k-steps
+constexpr int kChunkBytes = 128 * 16;               // one 16-byte K-chunk of the tile's 128 records
+constexpr int kTrStride = 33;                       // transposed 32 x 32 block of a wave, in doubles (odd: conflict free)
+constexpr int kMirrorBytes = 8 * 32 * kTrStride * 8;
 
-// c8[r][dpad] = (int8)counts[r][d], zero padded (rows n..npad-1, words dim..dpad-1);
-// rs[0][r] = S_r * (1/n_r * 1/n_r) with S_r = sum c^2 (exact integer), rs[1][r] = 1/n_r (0 for an empty
-// record); *maxcount = max over the matrix.  One wave per record, 4 words per lane and step.
-__global__ __launch_bounds__(256) void prep_i8_kernel(const uint32_t* __restrict__ counts,
-                                                      const unsigned long long* __restrict__ totals, uint64_t n,
-                                                      uint32_t dim, uint32_t dpad, int8_t* __restrict__ c8,
-                                                      double* __restrict__ rs, uint64_t npad,
-                                                      uint32_t* __restrict__ maxcount) {
-    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63;
-    if (r >= npad) return;
+// planes[p][q][r][16]: digit p of words 16q..16q+15 of record r;  rs: per-record terms;  *maxabs = max |v|.
+// A workgroup takes 16 records: thread (rr = t & 15, cl = t >> 4) packs the K-chunks cl, cl+16, .. of record rr,
+// so that the 16 threads of one chunk write 256 contiguous bytes.
+//   Eucl (SIGNED = false): v = counts;  rs[0][r] = S_r / n_r^2 (S exact), rs[1][r] = 1/n_r (0 for an empty record)
+//   SC   (SIGNED = true):  v = r2;      rs[0][r] = N_r = sum r2^2 (exact)
+template <bool SIGNED>
+__global__ __launch_bounds__(256) void prep_planes_kernel(const uint32_t* __restrict__ vals,
+                                                          const unsigned long long* __restrict__ totals, uint64_t n,
+                                                          uint32_t dim, uint32_t dpad, uint64_t npad,
+                                                          int8_t* __restrict__ planes, double* __restrict__ rs,
+                                                          uint32_t* __restrict__ maxabs) {
+    __shared__ unsigned long long sq_s[16];
+    __shared__ uint32_t mx_s[16];
+    const uint32_t t = threadIdx.x, rr = t & 15, cl = t >> 4;
+    const uint64_t r = (uint64_t)blockIdx.x * 16 + rr;
+    if (t < 16) { sq_s[t] = 0; mx_s[t] = 0; }
+    __syncthreads();
     unsigned long long sq = 0;
     uint32_t mx = 0;
+    const size_t plane = (size_t)npad * dpad;
     const bool vec = (dim & 3u) == 0;
-    for (uint32_t d = lane * 4; d < dpad; d += 256) {
-        uint32_t v[4] = {0, 0, 0, 0};
+    for (uint32_t q = cl; q < dpad / 16; q += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = 0;
         if (r < n) {
-            if (vec && d + 4 <= dim) {
-                const uint4 q = *reinterpret_cast<const uint4*>(counts + r * dim + d);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            const uint32_t d0 = q * 16;
+            if (vec && d0 + 16 <= dim) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint4 x = *reinterpret_cast<const uint4*>(vals + r * dim + d0 + 4 * g);
+                    v[4 * g] = x.x; v[4 * g + 1] = x.y; v[4 * g + 2] = x.z; v[4 * g + 3] = x.w;
+                }
             } else {
-                for (int e = 0; e < 4; ++e)
-                    if (d + e < dim) v[e] = counts[r * dim + d + e];
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (d0 + e < dim) v[e] = vals[r * dim + d0 + e];
             }
         }
-        uint32_t packed = 0;
+        uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            sq += (unsigned long long)v[e] * v[e];
-            mx = max(mx, v[e]);
-            packed |= min(v[e], 127u) << (8 * e);
+        for (int e = 0; e < 16; ++e) {
+            const int sv = (int)v[e];
+            const uint32_t a = SIGNED ? (uint32_t)(sv < 0 ? -sv : sv) : v[e];
+            sq += (unsigned long long)a * a;
+            mx = max(mx, a);
+            lo[e >> 2] |= (v[e] & 127u) << (8 * (e & 3));
+            hi[e >> 2] |= ((SIGNED ? (uint32_t)(sv >> 7) : (v[e] >> 7)) & 255u) << (8 * (e & 3));
         }
-        *reinterpret_cast<uint32_t*>(c8 + r * dpad + d) = packed;
+        *reinterpret_cast<uint4*>(planes + ((size_t)q * npad + r) * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *reinterpret_cast<uint4*>(planes + plane + ((size_t)q * npad + r) * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        sq += __shfl_down(sq, o, 64);
-        mx = max(mx, (uint32_t)__shfl_down(mx, o, 64));
+    if (sq) atomicAdd(&sq_s[rr], sq);
+    if (mx) atomicMax(&mx_s[rr], mx);
+    __syncthreads();
+    if (cl == 0) {
+        if (SIGNED) {
+            rs[r] = (double)sq_s[rr];
+        } else {
+            const unsigned long long tot = (r < n) ? totals[r] : 0ull;
+            const double inv = tot ? 1.0 / (double)tot : 0.0;
+            rs[r] = (double)sq_s[rr] * (inv * inv);
+            rs[npad + r] = inv;
+        }
     }
-    if (lane == 0) {
-        const unsigned long long tot = (r < n) ? totals[r] : 0ull;
-        const double inv = tot ? 1.0 / (double)tot : 0.0;
-        rs[r] = (double)sq * (inv * inv);
-        rs[npad + r] = inv;
-        if (mx > *maxcount) atomicMax(maxcount, mx);      // racy pre-check only skips redundant atomics
+    if (t == 0) {
+        uint32_t m = 0;
+        for (int i = 0; i < 16; ++i) m = max(m, mx_s[i]);
+        if (m > *maxabs) atomicMax(maxabs, m);            // racy pre-check only skips redundant atomics
     }
 }
 
-// One orientation of a wave's 64 x 64 block: rows = records r0.., columns = records c0...  Values go to
-// dst[(row - row_off) * ld + (col - col_off)]; `swap` says that rows are the block's columns (mirror).
-template <typename OUT>
-__device__ __forceinline__ void gram_i8_half(const po_tile_args& A, const int8_t* __restrict__ c8, uint32_t dpad,
-                                             const double* __restrict__ T, const double* __restrict__ inv,
-                                             uint64_t r0, uint64_t c0, bool swap, uint32_t lr, uint32_t lh) {
-    v16i g[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) g[m][q][e] = 0;
-    // lane holds 16 consecutive words of record (lr) starting at word 16*lh of the K step
-    const int8_t* pa = c8 + (r0 + lr) * dpad + 16 * lh;
-    const int8_t* pb = c8 + (c0 + lr) * dpad + 16 * lh;
-    for (uint32_t k0 = 0; k0 < dpad; k0 += 32) {
-        v4i a[2], b[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            a[m] = *reinterpret_cast<const v4i*>(pa + (uint64_t)m * 32 * dpad + k0);
-            b[m] = *reinterpret_cast<const v4i*>(pb + (uint64_t)m * 32 * dpad + k0);
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) g[m][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[q], g[m][q], 0, 0, 0);
+// P digit planes; runs iff  run_above < *maxabs <= run_upto  (maxabs == nullptr: always).
+template <int P, int METRIC, typename OUT>
+__global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(po_tile_args A, const int8_t* __restrict__ planes,
+                                                                               uint32_t dpad, const double* __restrict__ rs,
+                                                                               const uint32_t* __restrict__ maxabs,
+                                                                               long long run_above, long long run_upto) {
+    if (maxabs != nullptr) {
+        const long long m = *maxabs;
+        if (m <= run_above || m > run_upto) return;
     }
-    // accumulator layout (32x32): column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-    OUT* dst = static_cast<OUT*>(swap ? A.mirror : A.out);
-    const uint64_t ld = swap ? A.ld_mirror : A.ld_out;
-    const uint64_t row_off = swap ? A.col_begin : A.row_begin, col_off = swap ? A.row_begin : A.col_begin;
-    const uint64_t row_hi = min(A.n, swap ? A.col_end : A.row_end), col_hi = min(A.n, swap ? A.row_end : A.col_end);
-    // wave-uniform: is the whole 64 x 64 block inside the output block, and can it touch the diagonal?
-    const bool interior = r0 >= row_off && r0 + 64 <= row_hi && c0 >= col_off && c0 + 64 <= col_hi;
-    const bool on_diag = r0 == c0;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        double tr[16], ir[16];                            // row terms of this lane's 16 rows
-        const uint64_t rbase = r0 + m * 32 + 4 * lh;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const uint64_t r = rbase + (reg & 3) + 8 * (reg >> 2);
-            tr[reg] = T[r];
-            ir[reg] = inv[r];
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint64_t c = c0 + q * 32 + lr;
-            const double tc = T[c], ic = inv[c];
-            OUT* col = dst + (c - col_off);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const uint64_t r = rbase + (reg & 3) + 8 * (reg >> 2);
-                const double cross = (double)g[m][q][reg] * (ir[reg] * ic);   // symmetric in (r,c); = T for duplicates
-                double v = po_sqrt_nonneg(fmax((tr[reg] + tc) - 2.0 * cross, 0.0));
-                if (on_diag && r == c) v = 0.0;
-                if (interior || (r >= row_off && r < row_hi && c >= col_off && c < col_hi)) col[(r - row_off) * ld] = (OUT)v;
-            }
-        }
-    }
-}
-
-template <typename OUT>
-__global__ __launch_bounds__(kThreads, 2) void gram_i8_tile_kernel(po_tile_args A, const int8_t* __restrict__ c8,
-                                                                   uint32_t dpad, const double* __restrict__ rs,
-                                                                   const uint32_t* __restrict__ maxcount) {
-    if (*maxcount > 127u) return;                         // gram_tile_kernel<Eucl> owns the matrix
+    extern __shared__ __align__(16) unsigned char smem[];  // staging [P][A|B][8 chunks][128 records][16 B], then the mirror scratch
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & 63, wave = t >> 6;
-    const uint32_t wr = wave >> 1, wc = wave & 1;         // 2 x 2 waves of 64 x 64
+    const uint32_t wr = wave >> 1, wc = wave & 1;          // 4 x 2 waves of 32 x 64
+    const uint32_t lr = lane & 31, lh = lane >> 5;
     uint32_t ti, tj;
     po_tile_coords(A, TM, blockIdx.x, ti, tj);
-    const uint64_t i0 = (uint64_t)ti * TM + wr * 64, j0 = (uint64_t)tj * TN + wc * 64;
-    const double* T = rs;
-    const double* inv = rs + A.npad;
-    gram_i8_half<OUT>(A, c8, dpad, T, inv, i0, j0, false, lane & 31, lane >> 5);
-    if (po_tile_mirrors(A, ti, tj))                       // G^T = B A^T: same stores, rows <-> columns
-        gram_i8_half<OUT>(A, c8, dpad, T, inv, j0, i0, true, lane & 31, lane >> 5);
+    const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
+    const size_t plane = (size_t)A.npad * dpad;
+    constexpr int NG = P == 1 ? 1 : 3;                     // P == 2: [0] hi.hi, [1] hi.lo + lo.hi, [2] lo.lo
+    constexpr int HI = P - 1, LL = NG - 1;
+
+    v16i g[NG][2];
+#pragma unroll
+    for (int s = 0; s < NG; ++s)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) g[s][nn][e] = 0;
+
+    for (uint32_t k0 = 0; k0 < dpad; k0 += KCH) {
+        __syncthreads();                                   // the previous step's operand reads are done
+#pragma unroll
+        for (int u = 0; u < 4 * P; ++u) {                  // 32 P one-KiB LDS-DMA instructions, 4 P per wave
+            const uint32_t idx = wave * 4 * P + u;
+            const uint32_t p = idx >> 5, side = (idx >> 4) & 1, q = (idx >> 1) & 7, half = idx & 1;
+            const uint64_t rec = (side ? j0 : i0) + half * 64 + lane;
+            const int8_t* src = planes + p * plane + ((size_t)(k0 / 16 + q) * A.npad + rec) * 16;
+            po_glds16(src, smem + ((p * 2 + side) * 8 + q) * kChunkBytes + half * 1024);
+        }
+        __syncthreads();                                   // drains the LDS-DMA (vmcnt) of every wave
+#pragma unroll
+        for (int s = 0; s < KCH / 32; ++s) {
+            const uint32_t q = 2 * s + lh;                 // lane halves take the two 16-byte chunks of a k-step
+            v4i a[P], b[P][2];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                a[p] = *reinterpret_cast<const v4i*>(smem + ((p * 2 + 0) * 8 + q) * kChunkBytes + (wr * 32 + lr) * 16);
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn)
+                    b[p][nn] = *reinterpret_cast<const v4i*>(smem + ((p * 2 + 1) * 8 + q) * kChunkBytes + (wc * 64 + nn * 32 + lr) * 16);
+            }
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) {
+                if (P == 1) {
+                    g[0][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[0][nn], g[0][nn], 0, 0, 0);
+                } else {
+                    g[0][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[HI], b[HI][nn], g[0][nn], 0, 0, 0);
+                    g[HI][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[HI], b[0][nn], g[HI][nn], 0, 0, 0);
+                    g[HI][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[HI][nn], g[HI][nn], 0, 0, 0);
+                    g[LL][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[0][nn], g[LL][nn], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();                                       // the staging area becomes the mirror scratch
+
+    // ---- epilogue: accumulator layout (32x32): column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    OUT* out = static_cast<OUT*>(A.out);
+    OUT* mir = static_cast<OUT*>(A.mirror);
+    const bool mirror = po_tile_mirrors(A, ti, tj);
+    const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
+    const uint64_t iw = i0 + wr * 32, jw = j0 + wc * 64;
+    double* wl = reinterpret_cast<double*>(smem) + wave * (32 * kTrStride);
+    const double* t0 = rs;                                 // Eucl: S/n^2      SC: N
+    const double* t1 = rs + A.npad;                        // Eucl: 1/n
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+        const uint64_t c = jw + nn * 32 + lr;
+        const double tc = t0[c], ic = METRIC == PO_EUCL ? t1[c] : 0.0;
+        const bool c_ok = c >= A.col_begin && c < n_cols;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            const uint64_t r = iw + rl;
+            const double trr = t0[r], irr = METRIC == PO_EUCL ? t1[r] : 0.0;   // L1-resident row terms (registers are scarcer)
+            double G;
+            if (P == 1) G = (double)g[0][nn][reg];
+            else G = fma(16384.0, (double)g[0][nn][reg], fma(128.0, (double)g[HI][nn][reg], (double)g[LL][nn][reg]));
+            double v;
+            if (METRIC == PO_EUCL) {
+                const double cross = G * (irr * ic);       // symmetric in (r,c); equals S/n^2 for duplicates
+                v = po_sqrt_nonneg(fmax((trr + tc) - 2.0 * cross, 0.0));
+                if (r == c) v = 0.0;
+            } else {                                       // SC; a constant record has N = 0 -> NaN as SciPy gives
+                v = 1.0 - G / sqrt(trr * tc);
+            }
+            if (c_ok && r >= A.row_begin && r < n_rows) out[(r - A.row_begin) * A.ld_out + (c - A.col_begin)] = (OUT)v;
+            if (mirror) wl[lr * kTrStride + rl] = v;
+        }
+        if (mirror) {                                      // wave-private scratch; LDS operations of a wave run in order
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const uint32_t jr = it * 2 + lh;
+                const double w = wl[jr * kTrStride + lr];
+                const uint64_t cm = jw + nn * 32 + jr, r = iw + lr;
+                if (cm >= A.col_begin && cm < n_cols && r >= A.row_begin && r < n_rows)
+                    mir[(cm - A.col_begin) * A.ld_mirror + (r - A.row_begin)] = (OUT)w;
+            }
+        }
+    }
 }
 
-}  // namespace
-
-size_t po_gram_i8_workspace(uint64_t n, uint32_t dim) {
-    const uint64_t npad = po_round_up(n ? n : 1, 128);
-    return npad * po_round_up(dim, 32) + 2 * npad * sizeof(double) + 256;
-}
-
-// ws layout: int8 matrix | S, 1/n | maxcount
-int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
-                           uint64_t npad, void* ws, const uint32_t** flag_out) {
-    const uint32_t dpad = (uint32_t)po_round_up(dim, 32);
-    uint8_t* base = static_cast<uint8_t*>(ws);
-    int8_t* c8 = reinterpret_cast<int8_t*>(base);
-    double* rs = reinterpret_cast<double*>(base + npad * dpad);
-    uint32_t* maxcount = reinterpret_cast<uint32_t*>(base + npad * dpad + 2 * npad * sizeof(double));
-    PO_HIP(hipMemsetAsync(maxcount, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(prep_i8_kernel, dim3((uint32_t)((npad + 3) / 4)), dim3(256), 0, ctx->stream, d_counts,
-                       reinterpret_cast<const unsigned long long*>(d_totals), n, dim, dpad, c8, rs, npad, maxcount);
-    PO_CHECK_LAUNCH("prep_i8_kernel");
-    *flag_out = maxcount;
-    return PO_OK;
-}
-
-int po_launch_gram_i8_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint64_t* tiles) {
-    const uint32_t dpad = (uint32_t)po_round_up(a.dim, 32);
-    const uint8_t* base = static_cast<const uint8_t*>(ws);
-    const int8_t* c8 = reinterpret_cast<const int8_t*>(base);
-    const double* rs = reinterpret_cast<const double*>(base + a.npad * dpad);
-    const uint32_t* maxcount = reinterpret_cast<const uint32_t*>(base + a.npad * dpad + 2 * a.npad * sizeof(double));
+template <int P, int METRIC>
+int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint32_t dpad, const double* rs,
+                 const uint32_t* maxabs, long long run_above, long long run_upto, uint64_t* tiles) {
     const uint64_t nblocks = po_tile_count(a, TM);
     if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
-    if (a.out_f32)
-        hipLaunchKernelGGL(gram_i8_tile_kernel<float>, dim3((uint32_t)nblocks), dim3(kThreads), 0, ctx->stream, a, c8, dpad, rs, maxcount);
-    else
-        hipLaunchKernelGGL(gram_i8_tile_kernel<double>, dim3((uint32_t)nblocks), dim3(kThreads), 0, ctx->stream, a, c8, dpad, rs, maxcount);
+    const size_t staging = (size_t)P * 2 * 8 * kChunkBytes;
+    const size_t shmem = staging > (size_t)kMirrorBytes ? staging : (size_t)kMirrorBytes;
+    if (a.out_f32) {
+        auto k = gram_i8_tile_kernel<P, METRIC, float>;
+        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto);
+    } else {
+        auto k = gram_i8_tile_kernel<P, METRIC, double>;
+        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto);
+    }
     PO_CHECK_LAUNCH("gram_i8_tile_kernel");
     return PO_OK;
+}
+
+struct ws_view {
+    int8_t* planes;
+    double* rs;
+    uint32_t* maxabs;
+    uint32_t dpad;
+};
+
+ws_view view(void* ws, uint64_t npad, uint32_t dim) {
+    ws_view v;
+    v.dpad = (uint32_t)po_round_up(dim, KCH);
+    uint8_t* base = static_cast<uint8_t*>(ws);
+    v.planes = reinterpret_cast<int8_t*>(base);
+    v.rs = reinterpret_cast<double*>(base + 2 * (size_t)npad * v.dpad);
+    v.maxabs = reinterpret_cast<uint32_t*>(base + 2 * (size_t)npad * v.dpad + 2 * npad * sizeof(double));
+    return v;
+}
+
+}  // namespace
+
+// largest |value| two digit planes represent.  The int32 accumulators cannot overflow for any supported
+// dimension: the cross plane adds two products <= 127*127 per word, 2 * 16129 * 65536 < 2^31.
+uint32_t po_gram_i8_value_limit(uint32_t dim) { return dim <= 65536 ? 16383u : 127u; }
+bool po_gram_i8_sc_supported(uint32_t dim) { return dim >= 1 && dim <= 8191; }   // |2 #less + #equal - D| <= D - 1 < 8192
+
+size_t po_gram_i8_workspace(uint64_t n, uint32_t dim) {
+    const uint64_t npad = po_round_up(n ? n : 1, 128);
+    return 2 * npad * po_round_up(dim, KCH) + 2 * npad * sizeof(double) + 256;
+}
+
+// ws layout: plane lo | plane hi | rs[2][npad] | maxabs.   signed_values: vals are int32 (SC's r2), else uint32 counts.
+int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_vals, const uint64_t* d_totals, bool signed_values, uint64_t n,
+                           uint32_t dim, uint64_t npad, void* ws, const uint32_t** maxabs_out) {
+    const ws_view v = view(ws, npad, dim);
+    PO_HIP(hipMemsetAsync(v.maxabs, 0, sizeof(uint32_t), ctx->stream));
+    const dim3 grid((uint32_t)(npad / 16));
+    if (signed_values)
+        hipLaunchKernelGGL(prep_planes_kernel<true>, grid, dim3(256), 0, ctx->stream, d_vals, nullptr, n, dim, v.dpad, npad,
+                           v.planes, v.rs, v.maxabs);
+    else
+        hipLaunchKernelGGL(prep_planes_kernel<false>, grid, dim3(256), 0, ctx->stream, d_vals,
+                           reinterpret_cast<const unsigned long long*>(d_totals), n, dim, v.dpad, npad, v.planes, v.rs, v.maxabs);
+    PO_CHECK_LAUNCH("prep_planes_kernel");
+    if (maxabs_out) *maxabs_out = v.maxabs;
+    return PO_OK;
+}
+
+// Eucl: the one-plane kernel (max <= 127) and the two-plane kernel (127 < max <= limit) are both launched;
+// SC: two planes, unconditionally.
+int po_launch_gram_i8_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const void* ws, uint64_t* tiles) {
+    const ws_view v = view(const_cast<void*>(ws), a.npad, a.dim);
+    if (metric == PO_SC) return launch_tiles<2, PO_SC>(ctx, a, v.planes, v.dpad, v.rs, nullptr, 0, 0, tiles);
+    if (metric != PO_EUCL) { po_set_error("po_launch_gram_i8_tiles: metric %d is not a Gram-form metric", metric); return PO_EINVAL; }
+    int rc = launch_tiles<1, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, -1, 127, tiles);
+    if (rc) return rc;
+    const uint32_t limit = po_gram_i8_value_limit(a.dim);
+    if (limit > 127) rc = launch_tiles<2, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, 127, limit, nullptr);
+    return rc;
 }

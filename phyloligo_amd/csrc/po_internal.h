@@ -93,9 +93,9 @@ int po_launch_profile_distances(po_ctx* ctx, const uint32_t* d_counts, const uin
                                 const double* d_proto, int metric, double* d_out);
 
 // Working layout of stage 2: Ft[d][npad] = counts[n][d] / totals[n] (float64, zero padded).
-// skip_if_le127 (may be NULL): device word with the largest count; the kernel does nothing when it is <= 127
+// skip_flag (may be NULL): device word with the largest count; the kernel does nothing when it is <= skip_upto
 int po_launch_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
-                   uint64_t npad, double* d_ft, const uint32_t* skip_if_le127);
+                   uint64_t npad, double* d_ft, const uint32_t* skip_flag, uint32_t skip_upto);
 int po_launch_prep_freq(po_ctx* ctx, const double* d_freq, uint64_t n, uint32_t dim, uint64_t npad, double* d_ft);
 int po_launch_freq_rowmajor(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
                             uint32_t dim, double* d_freq);
@@ -137,22 +137,27 @@ int po_launch_bc_sad_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t*
                           uint64_t npad, void* ws, const unsigned long long** cls_out);
 int po_launch_bc_sad_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint64_t* tiles);
 size_t po_gram_i8_workspace(uint64_t n, uint32_t dim);
-int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
-                           uint64_t npad, void* ws, const uint32_t** flag_out);
-int po_launch_gram_i8_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint64_t* tiles);
-int po_launch_gram_norms(po_ctx* ctx, const double* ft, uint32_t dim, uint64_t npad, double* rowstat, const uint32_t* skip_if_le127);
+uint32_t po_gram_i8_value_limit(uint32_t dim);       // largest |value| the exact int8 kernels take (two 7-bit digits)
+bool po_gram_i8_sc_supported(uint32_t dim);          // Spearman's doubled centred ranks fit two digits
+// digit planes + per-record terms from uint32 counts (Eucl) or int32 doubled centred ranks (SC, signed_values)
+int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_vals, const uint64_t* d_totals, bool signed_values, uint64_t n,
+                           uint32_t dim, uint64_t npad, void* ws, const uint32_t** maxabs_out);
+int po_launch_gram_i8_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const void* ws, uint64_t* tiles);
+int po_launch_gram_norms(po_ctx* ctx, const double* ft, uint32_t dim, uint64_t npad, double* rowstat, const uint32_t* skip_flag,
+                         uint32_t skip_upto);
 // i8flag (may be NULL): device word holding the largest count; the float64 kernel leaves the matrix to the
-// int8 kernel when it is <= 127
-int po_launch_gram_f64(po_ctx* ctx, int metric, const po_tile_args& a, const uint32_t* i8flag, uint64_t* tiles);
+// int8 kernels when it is <= i8_upto
+int po_launch_gram_f64(po_ctx* ctx, int metric, const po_tile_args& a, const uint32_t* i8flag, uint32_t i8_upto, uint64_t* tiles);
 int po_logtab_init(po_ctx* ctx);
 
 // KT / SC helpers.  Order statistics of every record, from counts (uint32) or frequencies (float64):
 //   d_rt        centred average ranks, float64 [dim][npad]   (may be NULL)
 //   d_lessrank  number of strictly smaller words, uint32 [n][dim]: same order and ties as the
 //               input, which is all Kendall's tau looks at            (may be NULL)
+//   d_r2        2 #less + #equal - dim (twice the centred average rank), int32 [n][dim]   (may be NULL)
 //   rowstat[3]  number of tied word pairs of the record
 int po_launch_ranks(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint64_t n, uint32_t dim,
-                    uint64_t npad, double* d_rt, uint32_t* d_lessrank, double* d_rowstat);
+                    uint64_t npad, double* d_rt, uint32_t* d_lessrank, int32_t* d_r2, double* d_rowstat);
 int po_launch_kt(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, const po_tile_args& a,
                  uint64_t* tiles);
 

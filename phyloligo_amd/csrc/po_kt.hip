@@ -22,11 +22,12 @@ constexpr int kRow = CH + 1;      // +1: rows of a chunk start in different bank
 // One workgroup per record, input row major (uint32 counts or float64 frequencies).
 //   rt[d][npad]      centred average rank of word d:  #less + (#equal - D)/2
 //   lessrank[r][d]   #less (an integer with the order and ties of the input)
+//   r2[r][d]         2 #less + #equal - D = twice the centred average rank, an exact integer (po_gram_i8.hip)
 //   rowstat[3][r]    number of word pairs tied in the record
 template <typename T>
 __global__ __launch_bounds__(kThreads) void row_order_kernel(const T* __restrict__ rows, uint64_t n, uint32_t dim,
                                                              uint64_t npad, double* __restrict__ rt,
-                                                             uint32_t* __restrict__ lessrank,
+                                                             uint32_t* __restrict__ lessrank, int32_t* __restrict__ r2,
                                                              double* __restrict__ rowstat) {
     __shared__ T chunk[2048];
     __shared__ unsigned long long tied;
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(kThreads) void row_order_kernel(const T* __restrict
         if (d < dim) {
             if (rt) rt[(uint64_t)d * npad + r] = (double)less + 0.5 * ((double)equal - (double)dim);
             if (lessrank) lessrank[r * dim + d] = less;
+            if (r2) r2[r * dim + d] = (int32_t)(2u * less + equal) - (int32_t)dim;
             my_tied += equal - 1;                                    // ordered tied partners of word d
         }
     }
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void kt_tile_kernel(const uint32_t* __res
 }  // namespace
 
 int po_launch_ranks(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint64_t n, uint32_t dim,
-                    uint64_t npad, double* d_rt, uint32_t* d_lessrank, double* d_rowstat) {
+                    uint64_t npad, double* d_rt, uint32_t* d_lessrank, int32_t* d_r2, double* d_rowstat) {
     if (n == 0) return PO_OK;
     if (d_rt && (dim & 7u))   // operand rows are padded to a multiple of 8 words
         PO_HIP(hipMemsetAsync(d_rt + (uint64_t)dim * npad, 0, (po_round_up(dim, 8) - dim) * npad * sizeof(double), ctx->stream));
@@ -142,10 +144,10 @@ int po_launch_ranks(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq,
     }
     if (d_counts)
         hipLaunchKernelGGL(row_order_kernel<uint32_t>, dim3((uint32_t)n), dim3(kThreads), 0, ctx->stream, d_counts, n, dim,
-                           npad, d_rt, d_lessrank, d_rowstat);
+                           npad, d_rt, d_lessrank, d_r2, d_rowstat);
     else
         hipLaunchKernelGGL(row_order_kernel<double>, dim3((uint32_t)n), dim3(kThreads), 0, ctx->stream, d_freq, n, dim,
-                           npad, d_rt, d_lessrank, d_rowstat);
+                           npad, d_rt, d_lessrank, d_r2, d_rowstat);
     PO_CHECK_LAUNCH("row_order_kernel");
     return PO_OK;
 }

@@ -12,8 +12,8 @@ __global__ __launch_bounds__(256) void prep_transpose_kernel(const uint32_t* __r
                                                              const unsigned long long* __restrict__ totals,
                                                              uint64_t n, uint32_t dim, uint64_t npad,
                                                              double* __restrict__ ft,
-                                                             const uint32_t* __restrict__ skip_if_le127) {
-    if (skip_if_le127 != nullptr && *skip_if_le127 <= 127u) return;   // the int8 path needs no float64 operand
+                                                             const uint32_t* __restrict__ skip_flag, uint32_t skip_upto) {
+    if (skip_flag != nullptr && *skip_flag <= skip_upto) return;      // the int8 path needs no float64 operand
     __shared__ double tile[64][65];
     const uint64_t n0 = (uint64_t)blockIdx.x * 64;
     const uint32_t d0 = blockIdx.y * 64;
@@ -102,10 +102,10 @@ __global__ __launch_bounds__(256) void rowstat_kernel(const double* __restrict__
 }  // namespace
 
 int po_launch_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
-                   uint64_t npad, double* d_ft, const uint32_t* skip_if_le127) {
+                   uint64_t npad, double* d_ft, const uint32_t* skip_flag, uint32_t skip_upto) {
     dim3 grid((uint32_t)(npad / 64), (dim + 63) / 64);
     hipLaunchKernelGGL(prep_transpose_kernel, grid, dim3(256), 0, ctx->stream, d_counts,
-                       reinterpret_cast<const unsigned long long*>(d_totals), n, dim, npad, d_ft, skip_if_le127);
+                       reinterpret_cast<const unsigned long long*>(d_totals), n, dim, npad, d_ft, skip_flag, skip_upto);
     PO_CHECK_LAUNCH("prep_transpose_kernel");
     return PO_OK;
 }

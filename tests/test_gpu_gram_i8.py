@@ -1,0 +1,83 @@
+"""Exact int8-MFMA Gram kernels (csrc/po_gram_i8.hip): Euclidean distance with one digit plane (counts <= 127),
+two digit planes (counts <= 16383) and the float64 kernel beyond that; Spearman from doubled centred ranks."""
+import numpy as np
+import pytest
+
+from oracle import phyloligo_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-6, 1e-12
+I8, F64 = 4, 3           # PO_KERNEL_MFMA_I8_GRAM, PO_KERNEL_MFMA_F64_GRAM
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import phyloligo_amd as pa
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def random_counts(n, dim, top, seed, empty=(3,), dup=((5, 17),)):
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(0, max(2, top // 3), size=(n, dim), dtype=np.uint32)
+    counts[rng.random((n, dim)) < 0.2] = 0
+    counts[1, dim // 2] = top                       # the largest value decides which kernel runs
+    for e in empty:
+        counts[e] = 0
+    for a, b in dup:
+        counts[b] = counts[a]
+    return counts, counts.sum(1).astype(np.uint64)
+
+
+@pytest.mark.parametrize("top,kernel", [(127, I8), (128, I8), (5000, I8), (16383, I8), (16384, F64), (3_000_000, F64)])
+@pytest.mark.parametrize("dim", [16, 256, 200])
+def test_eucl_digit_planes(ctx, top, kernel, dim):
+    counts, totals = random_counts(300, dim, top, seed=top + dim)
+    got, st = ctx.pairwise(counts, totals, "Eucl", want_stats=True)
+    assert st["kernel_id"] == I8                    # both kernel families are launched; the device flag picks one
+    freq = oracle.counts_to_frequencies(counts.astype(np.int64), totals.astype(np.int64))
+    want = oracle.pairwise_block(freq, "Eucl")
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+    assert np.array_equal(got, got.T) and np.all(np.diag(got) == 0.0)
+    assert got[5, 17] == 0.0                        # duplicates: exactly 0, in every kernel
+    general = ctx.pairwise(counts, totals, "Eucl", table_path=False)
+    np.testing.assert_allclose(general, want, rtol=RTOL, atol=ATOL)
+    if kernel == I8 and top > 127:
+        # two planes: G is an exact integer, so the result does not depend on tiling or on the row range
+        sub = ctx.pairwise(counts, totals, "Eucl", row_begin=40, row_end=171)
+        assert np.array_equal(sub, got[40:171])
+        f32 = ctx.pairwise(counts, totals, "Eucl", dtype="float32")
+        assert np.array_equal(f32, got.astype(np.float32))
+
+
+@pytest.mark.parametrize("dim", [4, 64, 256, 1024, 4096])
+def test_spearman_int8_vs_float64_kernel_and_scipy(ctx, dim):
+    from scipy.stats import spearmanr
+    rng = np.random.default_rng(dim)
+    n = 140
+    counts = rng.integers(0, 12, size=(n, dim), dtype=np.uint32)          # many ties
+    counts[7] = 3                                                          # a constant record -> NaN
+    counts[9] = counts[2]
+    totals = counts.sum(1).astype(np.uint64)
+    got, st = ctx.pairwise(counts, totals, "SC", want_stats=True)
+    ref, st0 = ctx.pairwise(counts, totals, "SC", want_stats=True, table_path=False)
+    assert st["kernel_id"] == I8 and st0["kernel_id"] == F64
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12, equal_nan=True)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.isnan(got[7, 0]) and np.isnan(got[0, 7])
+    assert got[2, 9] == 0.0 and got[9, 2] == 0.0 and np.array_equal(got, got.T, equal_nan=True)
+    freq = counts / totals[:, None].astype(np.float64)
+    for i, j in [(0, 1), (3, 100), (50, 139), (2, 9)]:
+        want = 1.0 - spearmanr(freq[i], freq[j]).correlation
+        assert abs(got[i, j] - want) <= RTOL * abs(want) + ATOL
+    gf = ctx.pairwise_freq(freq, "SC")
+    np.testing.assert_allclose(gf, got, rtol=1e-12, atol=1e-15, equal_nan=True)
+
+
+def test_spearman_dimension_beyond_two_digits_uses_float64(ctx):
+    rng = np.random.default_rng(1)
+    freq = rng.random((40, 9000))
+    got, st = ctx.pairwise_freq(freq, "SC", want_stats=True)
+    assert st["kernel_id"] == F64
+    np.testing.assert_allclose(got, oracle.pairwise_block(freq, "SC"), rtol=RTOL, atol=ATOL)
