@@ -502,10 +502,21 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, nullptr, lessrank, nullptr, rowstat);
     }
     if (rc) return rc;
-    uint32_t kt_items = 0, kt_full_rounds = 0;
+    po_kt_mfma_plan kt_plan;
+    memset(&kt_plan, 0, sizeof(kt_plan));
     const bool kt_mfma = metric == PO_KT && po_kt_mfma_supported(dim) && !(flags & PO_FLAG_NO_TABLE_PATH);
     if (kt_mfma) {
-        rc = po_launch_kt_mfma_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, &kt_items, &kt_full_rounds);
+        // strand-symmetric records: Kendall's S over one word per reverse-complement orbit, weighted (po_fold.hip)
+        const uint32_t selfs = po_fold_selfs(dim);
+        const uint32_t* fold_src = nullptr;
+        if (!(flags & PO_FLAG_NO_RC_FOLD) && selfs != 0xFFFFFFFFu && po_kt_mfma_fold_supported(dim, selfs)) {
+            uint32_t dim_f = 0, at = 0;
+            rc = po_rc_fold(ctx, d_counts, d_freq, n, dim, PO_FOLD_SELFS_FIRST, &folded, &dim_f, &at);
+            if (rc) return rc;
+            if (folded) fold_src = static_cast<const uint32_t*>(ctx->ws_fold_src.p);
+        }
+        rc = po_launch_kt_mfma_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, fold_src, selfs, fold_src ? (dim - selfs) / 2 : 0,
+                                    &kt_plan);
         if (rc) return rc;
     }
     if (metric == PO_EUCL || (metric == PO_SC && !sc_i8)) {
@@ -578,7 +589,7 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
                 else { rc = po_launch_gram_f64(ctx, PO_SC, a, nullptr, 0, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; }
                 break;
             case PO_KT:
-                if (kt_mfma) { rc = po_launch_kt_mfma_tiles(ctx, a, ctx->ws_freq.p, kt_items, kt_full_rounds, &tiles); kid = PO_KERNEL_MFMA_I8_KT; }
+                if (kt_mfma) { rc = po_launch_kt_mfma_tiles(ctx, a, ctx->ws_freq.p, kt_plan, &tiles); kid = PO_KERNEL_MFMA_I8_KT; }
                 else { rc = po_launch_kt(ctx, lessrank, n, dim, a, &tiles); kid = PO_KERNEL_VALU_KT; }
                 break;
         }

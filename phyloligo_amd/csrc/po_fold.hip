@@ -108,6 +108,8 @@ static uint32_t log4_exact(uint32_t dim) {
 }
 
 // Builds (or reuses) the source-word table for (dim, gran) and reports the folded width and doubling point.
+// gran == PO_FOLD_SELFS_FIRST selects the layout of the Kendall kernel instead: [self-paired words | orbit
+// representatives], no padding in between, the row padded to 16 columns at the end (dbl_at = number of self-paired words).
 // *dim_f == 0: nothing to fold (dim is not a power of 4).
 static int fold_plan(po_ctx* ctx, uint32_t dim, uint32_t gran, uint32_t* dim_f, uint32_t* dbl_at) {
     *dim_f = 0;
@@ -125,9 +127,12 @@ static int fold_plan(po_ctx* ctx, uint32_t dim, uint32_t gran, uint32_t* dim_f, 
         if (w < r) pairs.push_back(w);
         else if (w == r) selfs.push_back(w);
     }
-    const uint32_t ppad = (uint32_t)po_round_up(pairs.size(), gran);
-    const uint32_t spad = (uint32_t)po_round_up(selfs.size(), 8);
+    const bool selfs_first = gran == PO_FOLD_SELFS_FIRST;
+    const uint32_t ppad = selfs_first ? (uint32_t)selfs.size() : (uint32_t)po_round_up(pairs.size(), gran);
+    const uint32_t spad = selfs_first ? (uint32_t)(po_round_up(selfs.size() + pairs.size(), 16) - selfs.size())
+                                      : (uint32_t)po_round_up(selfs.size(), 8);
     std::vector<uint32_t> src(ppad + spad, 0xFFFFFFFFu);
+    if (selfs_first) std::swap(pairs, selfs);            // first region: self-paired words, second: representatives
     for (size_t i = 0; i < pairs.size(); ++i) src[i] = pairs[i];
     for (size_t i = 0; i < selfs.size(); ++i) src[ppad + i] = selfs[i];
     int rc = po_buf_reserve(ctx, &ctx->ws_fold_src, src.size() * sizeof(uint32_t));
@@ -139,6 +144,13 @@ static int fold_plan(po_ctx* ctx, uint32_t dim, uint32_t gran, uint32_t* dim_f, 
     ctx->fold_dim_f = *dim_f = ppad + spad;
     ctx->fold_dbl_at = *dbl_at = ppad;
     return PO_OK;
+}
+
+// number of words that are their own reverse complement (4^(k/2) for even k, 0 for odd k); 0xFFFFFFFF when dim is not 4^k
+uint32_t po_fold_selfs(uint32_t dim) {
+    const uint32_t k = log4_exact(dim);
+    if (k == 0 || k > PO_MAX_K) return 0xFFFFFFFFu;
+    return (k & 1u) ? 0u : (1u << k);                      // 4^(k/2) = 2^k
 }
 
 // Folds counts (uint32) or frequencies (float64) into ctx->ws_fold if every record is reverse-complement

@@ -122,7 +122,9 @@ struct po_tile_args {
                             // po_fold.hip); 0xFFFFFFFF = never.  A multiple of the kernel's staging step.
 };
 #define PO_NO_DOUBLING 0xFFFFFFFFu
+#define PO_FOLD_SELFS_FIRST 0xFFFFu    // `gran` value of po_rc_fold selecting the Kendall layout [self-paired | representatives]
 // Reverse-complement folding of strand-symmetric inputs (JSD, BC); see po_fold.hip
+uint32_t po_fold_selfs(uint32_t dim);   // self-paired words of a 4^k word space (0xFFFFFFFF: dim is not 4^k)
 int po_rc_fold(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint64_t n, uint32_t dim, uint32_t gran,
                bool* folded, uint32_t* dim_f, uint32_t* dbl_at);
 // cls (may be NULL): per 128-record block, the common word total if the equal-total table path owns
@@ -163,10 +165,13 @@ int po_launch_kt(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t d
 
 // Kendall on the int8 matrix cores (dim <= 256)
 bool po_kt_mfma_supported(uint32_t dim);
+bool po_kt_mfma_fold_supported(uint32_t dim, uint32_t n_selfs);
 size_t po_kt_mfma_workspace(uint64_t n, uint32_t dim);
+struct po_kt_mfma_plan {
+    uint32_t n_items, words, row_bytes, dbl1, dbl2;
+};
 int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, uint64_t npad, void* ws,
-                           uint32_t* n_items_out, uint32_t* n_full_rounds_out);
-int po_launch_kt_mfma_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint32_t n_items, uint32_t n_full_rounds,
-                            uint64_t* tiles);
+                           const uint32_t* fold_src, uint32_t n_selfs, uint32_t n_pairs, po_kt_mfma_plan* plan);
+int po_launch_kt_mfma_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, const po_kt_mfma_plan& plan, uint64_t* tiles);
 
 static inline uint64_t po_round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }

@@ -29,11 +29,18 @@ constexpr int kThreads = 1024;              // waves 0-7 expand signs (two lanes
 constexpr int KS = 4;                       // K steps (32 word pairs each) per barrier
 constexpr int kSigStride = KS * 32 + 16;    // bytes per record in the sign tile (+16: conflict-free b128 rows)
 
+// rank8[r][c] = (uint8) lessrank[r][src ? src[c] : c], rows of `row_bytes` columns (zero beyond the words / records).
+// src = the folded column order of po_fold.hip: ranks among all D words keep the order and ties of the kept words.
 __global__ __launch_bounds__(256) void rank8_kernel(const uint32_t* __restrict__ lessrank, uint64_t n, uint32_t dim,
-                                                    uint64_t npad, uint8_t* __restrict__ rank8) {
-    const uint64_t total = npad * dim;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
-        rank8[i] = (i / dim < n) ? (uint8_t)lessrank[i] : (uint8_t)0;
+                                                    uint64_t npad, const uint32_t* __restrict__ src, uint32_t row_bytes,
+                                                    uint8_t* __restrict__ rank8) {
+    const uint64_t total = npad * row_bytes;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / row_bytes;
+        const uint32_t c = (uint32_t)(i - r * row_bytes);
+        const uint32_t w = src ? src[c] : c;                           // 0xFFFFFFFF: padding column
+        rank8[i] = (r < n && w < dim) ? (uint8_t)lessrank[r * dim + w] : (uint8_t)0;
+    }
 }
 
 // 4 packed bytes of ranks -> 4 packed sign bytes of (x_q - x_p).  one2 / mone2 = {1,1} / {-1,-1} in VGPRs
@@ -50,9 +57,12 @@ __device__ __forceinline__ uint32_t sign4(uint32_t w, uint32_t xp2, uint32_t one
 template <typename OUT>
 __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args A, const uint8_t* __restrict__ rank8,
                                                                    const uint16_t* __restrict__ items, uint32_t n_items,
-                                                                   uint32_t n_full_rounds) {
+                                                                   uint32_t row_bytes, uint32_t dim_full, uint32_t dbl1,
+                                                                   uint32_t dbl2) {
+    // A.dim = number of words the items range over (the folded count when dbl1/dbl2 are set), row_bytes = length of a
+    // rank row in memory (a multiple of 16 or A.dim), dim_full = D of the records (tie algebra of the epilogue).
     extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t rstride = A.dim + 16;                               // rank row stride in LDS (bytes)
+    const uint32_t rstride = row_bytes + 16;                           // rank row stride in LDS (bytes)
     unsigned char* ranks = smem;                                       // [256][rstride]
     unsigned char* sigma = smem + ((256 * rstride + 15) & ~15u);       // [2][256][kSigStride]
     uint16_t* litems = reinterpret_cast<uint16_t*>(sigma + 2 * 256 * kSigStride);   // [n_items] word-pair items
@@ -72,13 +82,13 @@ __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args 
     // ---- producer lane = one record: rank row into LDS (rows 0..127 = tile rows, 128..255 = tile columns) ----
     if (producer && half == 0) {
         const uint64_t rec = (t < 128) ? i0 + t : j0 + (t - 128);      // < npad: padded rows are zero
-        const uint8_t* src = rank8 + rec * A.dim;
+        const uint8_t* src = rank8 + rec * row_bytes;
         unsigned char* dst = ranks + t * rstride;
-        if ((A.dim & 15u) == 0) {
-            for (uint32_t d = 0; d < A.dim; d += 16) *reinterpret_cast<uint4*>(dst + d) = *reinterpret_cast<const uint4*>(src + d);
+        if ((row_bytes & 15u) == 0) {
+            for (uint32_t d = 0; d < row_bytes; d += 16) *reinterpret_cast<uint4*>(dst + d) = *reinterpret_cast<const uint4*>(src + d);
         } else {
-            for (uint32_t d = 0; d < A.dim; ++d) dst[d] = src[d];
-            for (uint32_t d = A.dim; d < ((A.dim + 15u) & ~15u); ++d) dst[d] = 0;
+            for (uint32_t d = 0; d < row_bytes; ++d) dst[d] = src[d];
+            for (uint32_t d = row_bytes; d < ((row_bytes + 15u) & ~15u); ++d) dst[d] = 0;
         }
     }
     for (uint32_t i = t; i < n_items; i += kThreads) litems[i] = items[i];
@@ -96,11 +106,12 @@ __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args 
     uint32_t one2, mone2;
     asm volatile("v_mov_b32 %0, 0x00010001" : "=v"(one2));
     asm volatile("v_mov_b32 %0, -1" : "=v"(mone2));
-    auto expand = [&](uint32_t item0, uint32_t buf, bool masked) {
+    auto expand = [&](uint32_t item0, uint32_t buf) {
         unsigned char* dst = sigma + (buf * 256 + (t & 255)) * kSigStride;
-        // this wave's KS item codes (wave uniform -> scalar registers)
+        // this wave's KS item codes (wave uniform -> scalar registers): (p << 8) | partial flag (bit 7) | q block
         const uint2 c2 = *reinterpret_cast<const uint2*>(litems + item0 + half * KS);
         const uint32_t cw[2] = {(uint32_t)__builtin_amdgcn_readfirstlane(c2.x), (uint32_t)__builtin_amdgcn_readfirstlane(c2.y)};
+        const bool masked = ((cw[0] | cw[1]) & 0x00800080u) != 0u;     // blocks lying wholly above their p need no masking
         // all LDS reads of the lane's KS items first (the sign-tile stores below may alias them for the
         // compiler, which would otherwise serialise read -> compute -> store item by item)
         uint32_t pp[KS], qq[KS], xps[KS];
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args 
         for (int it4 = 0; it4 < KS; ++it4) {                           // this lane's half of the round's 2 KS items
             const uint32_t code = (cw[it4 >> 1] >> (16 * (it4 & 1))) & 0xFFFFu;   // wave uniform: (p << 8) | qblock
             pp[it4] = code >> 8;
-            qq[it4] = code & 0xFFu;
+            qq[it4] = code & 0x0Fu;
             xps[it4] = myrank[pp[it4]];
             ws[it4] = *reinterpret_cast<const uint4*>(myrank + qq[it4] * 16);
         }
@@ -161,22 +172,34 @@ __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args 
     // rounds [0, n_full_rounds) hold only whole blocks (no masking code in the hot loop), the rest may be partial.
     // Producer waves write round r+1 into one sign buffer while the consumer waves, which share their SIMDs,
     // feed round r from the other buffer to the matrix cores: VALU expansion and MFMA overlap.
-    if (producer) expand(0, 0, n_full_rounds == 0);
+    // Folded operands (po_fold.hip): the items come in three classes - both words stand for two-word orbits
+    // (weight 4), one does (2), none does (1) - in that order; doubling the accumulators where a class ends
+    // gives 4 S4 + 2 S2 + S1 without touching the sign expansion.
+    auto double_sums = [&]() {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { g[m][e] <<= 1; gt[m][e] <<= 1; }
+    };
+    if (producer) expand(0, 0);
     __syncthreads();
     for (uint32_t r = 0; r < n_rounds; ++r) {
         const uint32_t buf = r & 1;
         if (producer) {
-            if (r + 1 < n_full_rounds) expand((r + 1) * 2 * KS, buf ^ 1, false);
-            else if (r + 1 < n_rounds) expand((r + 1) * 2 * KS, buf ^ 1, true);
+            if (r + 1 < n_rounds) expand((r + 1) * 2 * KS, buf ^ 1);
         } else {
+            if (r == dbl1) double_sums();
+            if (r == dbl2) double_sums();
             consume(buf);
         }
         __syncthreads();
     }
     if (producer) return;
+    if (dbl1 != PO_NO_DOUBLING && dbl1 >= n_rounds) double_sums();
+    if (dbl2 != PO_NO_DOUBLING && dbl2 >= n_rounds) double_sums();
 
     // ---- epilogue: tau = S / sqrt((T - t_r)(T - t_c)), KT = 1 - (1 - tau), 0 when a factor vanishes -----
-    const double T = 0.5 * (double)A.dim * ((double)A.dim - 1.0);
+    const double T = 0.5 * (double)dim_full * ((double)dim_full - 1.0);
     const double* ties = A.rowstat + 3 * A.npad;
     auto emit = [&](const v16i& acc, uint64_t r0, uint64_t c0, bool swap) {
         OUT* dst = static_cast<OUT*>(swap ? A.mirror : A.out);
@@ -210,59 +233,82 @@ __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args 
 }  // namespace
 
 bool po_kt_mfma_supported(uint32_t dim) { return dim <= 256; }
+// folded layout [self-paired words | orbit representatives]: the 16-word q blocks must not straddle the two regions
+bool po_kt_mfma_fold_supported(uint32_t dim, uint32_t n_selfs) { return dim <= 256 && (n_selfs % 16u) == 0; }
 
 size_t po_kt_mfma_workspace(uint64_t n, uint32_t dim) {
     const uint64_t npad = po_round_up(n ? n : 1, 128);
-    const size_t items = (size_t)dim * (dim / 16 + 2) + 16;
-    return npad * dim + items * sizeof(uint16_t) + 512;
+    const size_t items = (size_t)dim * (dim / 16 + 2) + 64;
+    return npad * po_round_up(dim, 16) + items * sizeof(uint16_t) + 512;
 }
 
-// ws layout: rank8[npad][dim] | items.  Returns the number of (padded) items.
+// ws layout: rank8[npad][row_bytes] | items.
+// fold_src != NULL: the records are reverse-complement symmetric (checked by po_rc_fold); only the words
+// fold_src[0 .. n_selfs + n_pairs) are kept, the first n_selfs standing for themselves, the others for two words each.
 int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, uint64_t npad, void* ws,
-                           uint32_t* n_items_out, uint32_t* n_full_rounds_out) {
+                           const uint32_t* fold_src, uint32_t n_selfs, uint32_t n_pairs, po_kt_mfma_plan* plan) {
+    const uint32_t words = fold_src ? n_selfs + n_pairs : dim;        // words the items range over
+    const uint32_t row_bytes = fold_src ? (uint32_t)po_round_up(words, 16) : dim;
     uint8_t* rank8 = static_cast<uint8_t*>(ws);
-    uint16_t* d_items = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(ws) + ((npad * dim + 255) & ~(uint64_t)255));
-    hipLaunchKernelGGL(rank8_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_lessrank, n, dim, npad, rank8);
+    uint16_t* d_items = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(ws) + ((npad * row_bytes + 255) & ~(uint64_t)255));
+    hipLaunchKernelGGL(rank8_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_lessrank, n, dim, npad, fold_src, row_bytes, rank8);
     PO_CHECK_LAUNCH("rank8_kernel");
-    // word pairs as items (p, block of 16 q): every block that contains a q in (p, dim).  Blocks lying wholly
-    // inside (p, dim) come first, in whole rounds; the partial ones (first block of a p, dim < 16), the left-over
-    // whole ones and fully-masked padding follow and go through the masking variant of the expansion.
-    static thread_local uint16_t host_items[256 * 18 + 32], partial[256 + 32];
-    uint32_t cnt = 0, npart = 0;
-    const uint32_t nblk = (dim + 15) / 16;
-    for (uint32_t p = 0; p + 1 < dim; ++p)
-        for (uint32_t qb = (p + 1) / 16; qb < nblk; ++qb) {
-            const bool whole = qb * 16 > p && qb * 16 + 16 <= dim;
-            if (whole) host_items[cnt++] = (uint16_t)((p << 8) | qb);
-            else partial[npart++] = (uint16_t)((p << 8) | qb);
-        }
-    const uint32_t full_rounds = cnt / (2 * KS);
-    for (uint32_t i = 0; i < npart; ++i) host_items[cnt++] = partial[i];
-    while (cnt == 0 || cnt % (2 * KS)) host_items[cnt++] = (uint16_t)(((dim - 1) << 8) | 0);   // fully masked padding
-    *n_full_rounds_out = full_rounds;
+    // word pairs as items (p, block of 16 q): every block that contains a q in (p, words).  Per weight class
+    // (4, 2, 1; a single class when not folded): blocks lying wholly inside (p, words) first, then the partial
+    // ones (flag bit 7: first block of a p, last block of the row), then fully masked padding up to a whole round.
+    static thread_local uint16_t host_items[256 * 18 + 96];
+    uint32_t cnt = 0;
+    const uint32_t nblk = (words + 15) / 16;
+    uint32_t class_start[4] = {0, 0, 0, 0};
+    const int n_classes = fold_src ? 3 : 1;
+    for (int cls = 0; cls < n_classes; ++cls) {
+        const uint32_t want = fold_src ? (4u >> cls) : 0u;             // 4, 2, 1
+        class_start[cls] = cnt / (2 * KS);
+        for (int partial = 0; partial < 2; ++partial)
+            for (uint32_t p = 0; p + 1 < words; ++p)
+                for (uint32_t qb = (p + 1) / 16; qb < nblk; ++qb) {
+                    if (fold_src) {
+                        const uint32_t w = (p < n_selfs ? 1u : 2u) * (qb * 16 < n_selfs ? 1u : 2u);
+                        if (w != want) continue;
+                    }
+                    const bool whole = qb * 16 > p && qb * 16 + 16 <= words;
+                    if (whole == (partial == 0)) host_items[cnt++] = (uint16_t)((p << 8) | (whole ? 0u : 0x80u) | qb);
+                }
+        while (cnt % (2 * KS)) host_items[cnt++] = (uint16_t)(((words - 1) << 8) | 0x80u);   // fully masked padding
+    }
+    while (cnt == 0) for (int i = 0; i < 2 * KS; ++i) host_items[cnt++] = (uint16_t)(((words - 1) << 8) | 0x80u);
+    class_start[n_classes] = cnt / (2 * KS);
     PO_HIP(hipMemcpyAsync(d_items, host_items, cnt * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
     PO_HIP(hipStreamSynchronize(ctx->stream));                        // host_items is reused by the next call
-    *n_items_out = cnt;
+    plan->n_items = cnt;
+    plan->words = words;
+    plan->row_bytes = row_bytes;
+    plan->dbl1 = fold_src ? class_start[1] : PO_NO_DOUBLING;          // == number of rounds when the later classes are empty
+    plan->dbl2 = fold_src ? class_start[2] : PO_NO_DOUBLING;
     return PO_OK;
 }
 
-int po_launch_kt_mfma_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint32_t n_items, uint32_t n_full_rounds,
-                            uint64_t* tiles) {
+int po_launch_kt_mfma_tiles(po_ctx* ctx, const po_tile_args& a_in, const void* ws, const po_kt_mfma_plan& plan, uint64_t* tiles) {
+    po_tile_args a = a_in;
+    const uint32_t dim_full = a.dim;
+    a.dim = plan.words;
     const uint8_t* rank8 = static_cast<const uint8_t*>(ws);
-    const uint16_t* d_items = reinterpret_cast<const uint16_t*>(static_cast<const uint8_t*>(ws) + ((a.npad * a.dim + 255) & ~(uint64_t)255));
+    const uint16_t* d_items = reinterpret_cast<const uint16_t*>(static_cast<const uint8_t*>(ws) + ((a.npad * plan.row_bytes + 255) & ~(uint64_t)255));
     const uint64_t nblocks = po_tile_count(a, TM);
     if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
-    const size_t shmem = ((256 * (a.dim + 16) + 15) & ~(size_t)15) + 2 * 256 * kSigStride + ((n_items * 2 + 15) & ~(size_t)15);
+    const size_t shmem = ((256 * (plan.row_bytes + 16) + 15) & ~(size_t)15) + 2 * 256 * kSigStride + ((plan.n_items * 2 + 15) & ~(size_t)15);
     if (a.out_f32) {
         auto k = kt_mfma_tile_kernel<float>;
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, rank8, d_items, n_items, n_full_rounds);
+        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, rank8, d_items, plan.n_items,
+                           plan.row_bytes, dim_full, plan.dbl1, plan.dbl2);
     } else {
         auto k = kt_mfma_tile_kernel<double>;
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, rank8, d_items, n_items, n_full_rounds);
+        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, rank8, d_items, plan.n_items,
+                           plan.row_bytes, dim_full, plan.dbl1, plan.dbl2);
     }
     PO_CHECK_LAUNCH("kt_mfma_tile_kernel");
     return PO_OK;

@@ -145,7 +145,7 @@ def test_other_metrics_ignore_the_fold(ctx):
     contigs = contigs_ragged(90, 21)
     seq, off = pack(contigs)
     counts, totals = ctx.count_profiles(seq, off, "1111", "both")
-    for metric in ("Eucl", "SC", "KT"):
+    for metric in ("Eucl", "SC"):
         _, st = ctx.pairwise(counts, totals, metric, want_stats=True)
         assert not st["rc_folded"]
 
@@ -163,3 +163,39 @@ def test_long_rows_fold_without_lds_staging(ctx):
         np.testing.assert_allclose(folded, plain, rtol=1e-9, atol=2e-11, equal_nan=True)
         freq = oracle.counts_to_frequencies(counts.astype(np.int64), totals.astype(np.int64))
         np.testing.assert_allclose(folded, oracle.pairwise_block(freq, metric), rtol=RTOL, atol=ATOL, equal_nan=True)
+
+
+@pytest.mark.parametrize("pattern,expect_fold", [("1111", True), ("111", True), ("1", True), ("11", False), ("1001", False),
+                                                 ("101", False), ("11011", True), ("1101", False)])
+def test_kendall_folds_exactly(ctx, pattern, expect_fold):
+    """Kendall's S is an integer: the weighted sum over orbit representatives must reproduce the full sum bit for bit.
+    k = 2 (4 self-paired words: the 16-word blocks would straddle the regions) and k > 4 (no int8 kernel) do not fold."""
+    contigs = contigs_ragged(140, 31, lo=200, hi=1500)
+    seq, off = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, off, pattern, "both")
+    got, st = ctx.pairwise(counts, totals, "KT", want_stats=True)
+    plain, st0 = ctx.pairwise(counts, totals, "KT", want_stats=True, rc_fold=False)
+    assert st["rc_folded"] == expect_fold and not st0["rc_folded"]
+    assert np.array_equal(got, plain, equal_nan=True)
+    valu = ctx.pairwise(counts, totals, "KT", table_path=False)
+    assert np.array_equal(got, valu, equal_nan=True)
+    sub = ctx.pairwise(counts, totals, "KT", row_begin=3, row_end=77)
+    assert np.array_equal(sub, got[3:77], equal_nan=True)
+    gf, stf = ctx.pairwise_freq(ctx.frequencies(counts, totals), "KT", want_stats=True)
+    assert stf["rc_folded"] == expect_fold and np.array_equal(gf, got, equal_nan=True)
+    if counts.shape[1] <= 64:
+        from scipy.stats import kendalltau
+        freq = ctx.frequencies(counts, totals)
+        for i, j in [(0, 1), (2, 5), (20, 99)]:
+            tau = kendalltau(freq[i], freq[j], variant="b").statistic
+            want = 0.0 if np.isnan(tau) else tau
+            assert abs(got[i, j] - want) < 1e-12
+
+
+def test_kendall_single_strand_not_folded(ctx):
+    contigs = contigs_ragged(60, 8)
+    seq, off = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, off, "1111", "plus")
+    got, st = ctx.pairwise(counts, totals, "KT", want_stats=True)
+    assert not st["rc_folded"]
+    assert np.array_equal(got, ctx.pairwise(counts, totals, "KT", table_path=False), equal_nan=True)
