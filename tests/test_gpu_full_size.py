@@ -1,0 +1,73 @@
+"""BASELINE.json's full-size configurations (50 000 contigs x 2 kb) on one GPU, checked through properties that do
+not need an O(N^2) oracle: exact symmetry, diagonal, value range, agreement of independent code paths
+(row-block call vs full matrix, folded vs unfolded operands), and a few complete rows against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import phyloligo_oracle as oracle
+from phyloligo_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+N = 50_000
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import phyloligo_amd as pa
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def profiles(ctx, pattern, seed):
+    import torch
+    seq, off = synthetic.contig_bytes(N, 2000, seed=seed)
+    dseq = torch.from_numpy(seq.copy()).cuda()
+    doff = torch.from_numpy(off.astype(np.int64)).cuda()
+    return ctx.count_profiles(dseq, doff, pattern, "both")
+
+
+def is_symmetric(out, block=8192):
+    import torch
+    n = out.shape[0]
+    for i in range(0, n, block):
+        for j in range(i, n, block):
+            a = out[i:i + block, j:j + block]
+            b = out[j:j + block, i:i + block].T
+            if not torch.equal(a, b):
+                return False
+    return True
+
+
+@pytest.mark.parametrize("config,pattern,metric,seed,lo,hi", [
+    ("C2", "1111", "JSD", 50001, 0.0, float(np.log(2.0))),
+    ("C3", "1111", "Eucl", 50001, 0.0, float(np.sqrt(2.0))),
+    ("C5", "11011011", "BC", 50005, 0.0, 1.0),
+])
+def test_full_size_matrix_properties(ctx, config, pattern, metric, seed, lo, hi):
+    import torch
+    counts, totals = profiles(ctx, pattern, seed)
+    assert int(totals.min()) == int(totals.max()) == 2 * (2000 - len(pattern) + 1) + len(pattern) - 1   # 3 997 / 3 993
+    out = torch.empty((N, N), dtype=torch.float64, device="cuda")
+    _, st = ctx.pairwise(counts, totals, metric, out=out, want_stats=True)
+    assert st["pairs"] == N * N // 2 and st["rc_folded"] == (metric != "Eucl")
+    assert is_symmetric(out)
+    assert bool((torch.diagonal(out) == 0).all())
+    assert float(out.min()) >= lo and float(out.max()) <= hi * (1 + 1e-12)
+    assert not bool(torch.isnan(out).any())
+    # independent paths: a row block computed without the symmetry shortcut, and the unfolded operands
+    sub = ctx.pairwise(counts, totals, metric, row_begin=31_000, row_end=31_300)
+    assert torch.equal(sub, out[31_000:31_300]) if metric != "JSD" else torch.allclose(sub, out[31_000:31_300], rtol=1e-12, atol=1e-15)
+    plain = ctx.pairwise(counts, totals, metric, row_begin=7, row_end=135, rc_fold=False)
+    assert torch.allclose(plain, out[7:135], rtol=1e-9, atol=1e-13)
+    # complete rows against the oracle
+    freq = oracle.counts_to_frequencies(counts.cpu().numpy().astype(np.int64), totals.cpu().numpy())
+    for r in (0, 24_999, N - 1):
+        want = oracle.pairwise_block(np.vstack([freq[r:r + 1], freq]), metric, 0, 1)[0, 1:]
+        want[r] = 0.0
+        np.testing.assert_allclose(out[r].cpu().numpy(), want, rtol=1e-6, atol=1e-12)
+    # a checksum of checksums: row sums equal column sums exactly (symmetry) and their total is reproducible
+    rs, cs = out.sum(dim=1), out.sum(dim=0)
+    assert torch.allclose(rs, cs, rtol=1e-12)
+    del out
+    torch.cuda.empty_cache()
