@@ -7,7 +7,7 @@ from phyloligo_amd import synthetic
 ctx = pa.Context(0)
 print(ctx.device_name)
 configs = [("C1", 1000, "1111", "Eucl", 1001), ("C2", 50000, "1111", "JSD", 50001), ("C3", 50000, "1111", "Eucl", 50001),
-           ("C5", 50000, "11011011", "BC", 50005), ("C2-KT", 2000, "1111", "KT", 50001), ("C2-SC", 50000, "1111", "SC", 50001)]
+           ("C5", 50000, "11011011", "BC", 50005), ("C2-KT", 50000, "1111", "KT", 50001), ("C2-SC", 50000, "1111", "SC", 50001)]
 only = sys.argv[1].split(",") if len(sys.argv) > 1 else None
 for name, n, pat, metric, seed in configs:
     if only and name not in only: continue
