@@ -157,10 +157,13 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) ni[m][reg] = norms[iw + m * 16 + lg + 4 * reg];
+    double njs[4];                                         // all loads before the first store: on gfx9 loads and stores
+#pragma unroll                                             // share the in-order vmcnt counter
+    for (int n = 0; n < 4; ++n) njs[n] = norms[jw + n * 16 + lc];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const uint64_t j = jw + n * 16 + lc;
-        const double nj = norms[j];
+        const double nj = njs[n];
         const bool j_ok = j >= A.col_begin && j < n_cols;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {

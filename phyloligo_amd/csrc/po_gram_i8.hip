@@ -34,6 +34,7 @@ constexpr int KCH = 128;                            // bytes of K per record and
 constexpr int kChunkBytes = 128 * 16;               // one 16-byte K-chunk of the tile's 128 records
 constexpr int kTrStride = 33;                       // transposed 32 x 32 block of a wave, in doubles (odd: conflict free)
 constexpr int kMirrorBytes = 8 * 32 * kTrStride * 8;
+constexpr int kTermBytes = 4 * 128 * 8;             // per-record terms of the tile's rows and columns, read by the epilogue
 
 // planes[p][q][r][16]: digit p of words 16q..16q+15 of record r;  rs: per-record terms;  *maxabs = max |v|.
 // A workgroup takes 16 records: thread (rr = t & 15, cl = t >> 4) packs the K-chunks cl, cl+16, .. of record rr,
@@ -173,6 +174,15 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
         }
     }
     __syncthreads();                                       // the staging area becomes the mirror scratch
+    // per-record terms into LDS: on gfx9 loads and stores share one in-order counter (vmcnt), so a global load
+    // issued among the output stores could only be waited for together with every store before it
+    double* terms = reinterpret_cast<double*>(smem + kMirrorBytes);      // [t0 rows | t0 cols | t1 rows | t1 cols]
+    if (t < 256) {
+        const uint64_t rec = (t < 128) ? i0 + t : j0 + (t - 128);
+        terms[t] = rs[rec];
+        terms[256 + t] = METRIC == PO_EUCL ? rs[A.npad + rec] : 0.0;
+    }
+    __syncthreads();
 
     // ---- epilogue: accumulator layout (32x32): column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     OUT* out = static_cast<OUT*>(A.out);
@@ -181,18 +191,18 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
     const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
     const uint64_t iw = i0 + wr * 32, jw = j0 + wc * 64;
     double* wl = reinterpret_cast<double*>(smem) + wave * (32 * kTrStride);
-    const double* t0 = rs;                                 // Eucl: S/n^2      SC: N
-    const double* t1 = rs + A.npad;                        // Eucl: 1/n
+    const double* t0r = terms + wr * 32, *t0c = terms + 128 + wc * 64;          // Eucl: S/n^2      SC: N
+    const double* t1r = terms + 256 + wr * 32, *t1c = terms + 384 + wc * 64;    // Eucl: 1/n
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
         const uint64_t c = jw + nn * 32 + lr;
-        const double tc = t0[c], ic = METRIC == PO_EUCL ? t1[c] : 0.0;
+        const double tc = t0c[nn * 32 + lr], ic = METRIC == PO_EUCL ? t1c[nn * 32 + lr] : 0.0;
         const bool c_ok = c >= A.col_begin && c < n_cols;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             const uint64_t r = iw + rl;
-            const double trr = t0[r], irr = METRIC == PO_EUCL ? t1[r] : 0.0;   // L1-resident row terms (registers are scarcer)
+            const double trr = t0r[rl], irr = METRIC == PO_EUCL ? t1r[rl] : 0.0;
             double G;
             if (P == 1) G = (double)g[0][nn][reg];
             else G = fma(16384.0, (double)g[0][nn][reg], fma(128.0, (double)g[HI][nn][reg], (double)g[LL][nn][reg]));
@@ -202,7 +212,13 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
                 v = po_sqrt_nonneg(fmax((trr + tc) - 2.0 * cross, 0.0));
                 if (r == c) v = 0.0;
             } else {                                       // SC; a constant record has N = 0 -> NaN as SciPy gives
-                v = 1.0 - G / sqrt(trr * tc);
+                // G / sqrt(N_r N_c) as G * rsqrt: v_rsq_f64 seed + two Newton steps (~1 ulp) instead of the
+                // ~40-instruction sqrt + divide; identical records (G = N_r = N_c, exact integers) give exactly 0
+                const double x = trr * tc;
+                double y = __builtin_amdgcn_rsq(x);
+                y = fma(0.5 * y, fma(-(x * y), y, 1.0), y);
+                y = fma(0.5 * y, fma(-(x * y), y, 1.0), y);
+                v = (G == trr && G == tc) ? (x > 0.0 ? 0.0 : G / x) : 1.0 - G * y;
             }
             if (c_ok && r >= A.row_begin && r < n_rows) out[(r - A.row_begin) * A.ld_out + (c - A.col_begin)] = (OUT)v;
             if (mirror) wl[lr * kTrStride + rl] = v;
@@ -228,7 +244,7 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
     const size_t staging = (size_t)P * 2 * 8 * kChunkBytes;
-    const size_t shmem = staging > (size_t)kMirrorBytes ? staging : (size_t)kMirrorBytes;
+    const size_t shmem = (staging > (size_t)kMirrorBytes ? staging : (size_t)kMirrorBytes) + kTermBytes;
     if (a.out_f32) {
         auto k = gram_i8_tile_kernel<P, METRIC, float>;
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));

@@ -208,10 +208,13 @@ __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args 
         const uint64_t row_hi = min(A.n, swap ? A.col_end : A.row_end), col_hi = min(A.n, swap ? A.row_end : A.col_end);
         const uint64_t c = c0 + lr;
         const double dc = T - ties[min(c, A.npad - 1)];
+        double drs[16];                                    // every load before the first store (shared in-order vmcnt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) drs[reg] = T - ties[min(r0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh, A.npad - 1)];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const uint64_t rr = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            const double dr = T - ties[min(rr, A.npad - 1)];
+            const double dr = drs[reg];
             double v;
             if (dr == 0.0 || dc == 0.0) {
                 v = 1.0 - 1.0;
