@@ -30,7 +30,13 @@ __device__ __forceinline__ double po_lds_read_f64(uint32_t addr) {
 __device__ __forceinline__ void po_glds16(const void* gptr, void* lds_base) {
     __builtin_amdgcn_global_load_lds((po_glb_byte*)gptr, (po_lds_byte*)lds_base, 16, 0, 0);
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which on gfx9
+// (loads and stores share the in-order vmcnt counter) makes every wave wait for all of its outstanding GLOBAL
+// stores as well - in an epilogue that alternates LDS transposes with output stores that is one full store
+// latency per barrier.  Not for loops that stage with LDS-DMA (those complete on vmcnt).
+__device__ __forceinline__ void po_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #else
+__device__ __forceinline__ void po_lds_barrier() {}
 __device__ __forceinline__ uint32_t po_lds_addr(const void*) { return 0; }
 __device__ __forceinline__ double2 po_lds_read_d2(uint32_t) { return make_double2(0.0, 0.0); }
 __device__ __forceinline__ double po_lds_read_f64(uint32_t) { return 0.0; }
@@ -183,12 +189,12 @@ __device__ __forceinline__ void po_store_block(const po_tile_args& A, uint32_t t
                          (reinterpret_cast<uintptr_t>(A.mirror) & 15) == 0 && i0 >= A.row_begin;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        __syncthreads();
+        po_lds_barrier();                                             // LDS only: the stores above stay in flight
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int ia = 0; ia < RPT; ++ia) lds[(2 * tx + e) * kMirrorLdsStride + ty * RPT + ia] = v[ia][2 * q + e];
-        __syncthreads();
+        po_lds_barrier();
         for (uint32_t jq = wave; jq < 32; jq += NT / 64) {           // one wave per transposed row
             const uint64_t j = j0 + 32 * q + jq;
             if (j < A.col_begin || j >= n_cols) continue;
