@@ -1,0 +1,35 @@
+"""One launch of every stage-2 tile kernel at N = 50 000 (for rocprofv3 --pmc passes; see tools/pmc_busy.py)."""
+import sys
+import numpy as np, torch
+sys.path.insert(0, '.')
+import phyloligo_amd as pa
+from phyloligo_amd import synthetic
+
+ctx = pa.Context(0)
+n = 50000
+out = torch.empty((n, n), dtype=torch.float64, device="cuda")
+
+
+def profiles(pattern, seed, ragged=False):
+    if ragged:
+        rng = np.random.default_rng(seed)
+        lens = rng.integers(1500, 2500, size=n)
+        off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum(lens)
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(off[-1]), dtype=np.uint8)]
+    else:
+        seq, off = synthetic.contig_bytes(n, 2000, seed=seed)
+    dseq = torch.from_numpy(np.ascontiguousarray(seq)).cuda(); doff = torch.from_numpy(off.astype(np.int64)).cuda()
+    return ctx.count_profiles(dseq, doff, pattern, "both")
+
+
+c, t = profiles("1111", 50001)
+for metric in ("JSD", "Eucl", "BC", "SC", "KT"):
+    ctx.pairwise(c, t, metric, out=out)
+ctx.pairwise(c, t, "Eucl", out=out, table_path=False)          # float64 MFMA Gram
+c, t = profiles("1111", 50002, ragged=True)
+ctx.pairwise(c, t, "JSD", out=out)                                # general JSD kernel
+ctx.pairwise(c, t, "BC", out=out)                                 # general BC kernel
+c, t = profiles("11011011", 50005)
+ctx.pairwise(c, t, "BC", out=out)                                 # C5
+torch.cuda.synchronize()
+print("done")
