@@ -154,6 +154,8 @@ __device__ __forceinline__ bool po_tile_mirrors(const po_tile_args& A, uint32_t 
 // columns j0 + 32*(ib>>1) + 2*tx + (ib&1).  The tile goes out as 16-byte stores along rows (16 lanes =
 // 256 contiguous bytes); the mirrored tile is transposed through LDS, 32 columns at a time, so that it
 // too leaves as full contiguous row segments (one wave = one 1 KiB row piece) instead of 64-byte crumbs.
+__device__ __forceinline__ void po_store2(double* p, double a, double b) { *reinterpret_cast<double2*>(p) = make_double2(a, b); }
+__device__ __forceinline__ void po_store2(float* p, double a, double b) { *reinterpret_cast<float2*>(p) = make_float2((float)a, (float)b); }
 constexpr int kMirrorLdsStride = 130;                                 // doubles per transposed row (128 + pad)
 constexpr int kMirrorLdsBytes = 32 * kMirrorLdsStride * 8;           // 33 280 B of LDS scratch
 
@@ -163,8 +165,9 @@ __device__ __forceinline__ void po_store_block(const po_tile_args& A, uint32_t t
     OUT* out = static_cast<OUT*>(A.out);
     const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
     // ---- the tile itself ----
-    const bool vec_out = sizeof(OUT) == 8 && (A.ld_out & 1) == 0 && ((j0 - A.col_begin) & 1) == 0 &&
-                         (reinterpret_cast<uintptr_t>(A.out) & 15) == 0 && j0 >= A.col_begin;
+    // two adjacent columns per lane leave as one 16-byte (float64) or 8-byte (float32) store
+    const bool vec_out = (A.ld_out & 1) == 0 && ((j0 - A.col_begin) & 1) == 0 &&
+                         (reinterpret_cast<uintptr_t>(A.out) & (2 * sizeof(OUT) - 1)) == 0 && j0 >= A.col_begin;
 #pragma unroll
     for (int ia = 0; ia < RPT; ++ia) {
         const uint64_t i = i0 + ty * RPT + ia;
@@ -174,7 +177,7 @@ __device__ __forceinline__ void po_store_block(const po_tile_args& A, uint32_t t
         for (int q = 0; q < 4; ++q) {
             const uint64_t j = j0 + 32 * q + 2 * tx;
             if (vec_out && j + 1 < n_cols) {
-                *reinterpret_cast<double2*>(row + (j - A.col_begin)) = make_double2(v[ia][2 * q], v[ia][2 * q + 1]);
+                po_store2(row + (j - A.col_begin), v[ia][2 * q], v[ia][2 * q + 1]);
             } else {
                 if (j >= A.col_begin && j < n_cols) row[j - A.col_begin] = (OUT)v[ia][2 * q];
                 if (j + 1 >= A.col_begin && j + 1 < n_cols) row[j + 1 - A.col_begin] = (OUT)v[ia][2 * q + 1];
@@ -185,8 +188,8 @@ __device__ __forceinline__ void po_store_block(const po_tile_args& A, uint32_t t
     // ---- the transposed tile ----
     OUT* mir = static_cast<OUT*>(A.mirror);
     const uint32_t t = ty * 16 + tx, lane = t & 63, wave = t >> 6;
-    const bool vec_mir = sizeof(OUT) == 8 && (A.ld_mirror & 1) == 0 && ((i0 - A.row_begin) & 1) == 0 &&
-                         (reinterpret_cast<uintptr_t>(A.mirror) & 15) == 0 && i0 >= A.row_begin;
+    const bool vec_mir = (A.ld_mirror & 1) == 0 && ((i0 - A.row_begin) & 1) == 0 &&
+                         (reinterpret_cast<uintptr_t>(A.mirror) & (2 * sizeof(OUT) - 1)) == 0 && i0 >= A.row_begin;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         po_lds_barrier();                                             // LDS only: the stores above stay in flight
@@ -202,7 +205,7 @@ __device__ __forceinline__ void po_store_block(const po_tile_args& A, uint32_t t
             const uint64_t i = i0 + 2 * lane;
             OUT* row = mir + (j - A.col_begin) * A.ld_mirror;
             if (vec_mir && i + 1 < n_rows) {
-                *reinterpret_cast<double2*>(row + (i - A.row_begin)) = w;
+                po_store2(row + (i - A.row_begin), w.x, w.y);
             } else {
                 if (i >= A.row_begin && i < n_rows) row[i - A.row_begin] = (OUT)w.x;
                 if (i + 1 >= A.row_begin && i + 1 < n_rows) row[i + 1 - A.row_begin] = (OUT)w.y;
