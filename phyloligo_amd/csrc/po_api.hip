@@ -526,7 +526,7 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     if (metric == PO_JSD && d_counts && !(flags & PO_FLAG_NO_TABLE_PATH)) {
         // record blocks with one common word total go through the integer-sum table kernel, the rest
         // through the general float64 kernel; each launch skips the other's tiles (decided on device)
-        rc = po_launch_jsd_lut_prep(ctx, d_counts, d_totals, n, dim, npad, ctx->ws_aux.p, &cls);
+        rc = po_launch_jsd_lut_prep(ctx, d_counts, d_totals, n, dim, npad, rowstat + npad, ctx->ws_aux.p, &cls);
         if (rc) return rc;
     }
     if (metric == PO_BC && d_counts && !(flags & PO_FLAG_NO_TABLE_PATH)) {

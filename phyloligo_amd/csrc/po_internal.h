@@ -131,8 +131,9 @@ int po_rc_fold(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint
 // the tiles of that class (po_jsd_lut.hip); valu_tile_kernel<JSD> skips tiles with equal non-zero classes.
 int po_launch_valu_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const unsigned long long* cls, uint64_t* tiles);
 size_t po_jsd_lut_workspace(uint64_t n, uint32_t dim);
+// d_wsum: rowstat[1] = sum_w f of every record (po_launch_rowstat must have run)
 int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
-                           uint64_t npad, void* ws, const unsigned long long** cls_out);
+                           uint64_t npad, const double* d_wsum, void* ws, const unsigned long long** cls_out);
 int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, const void* ws, uint64_t* tiles);
 size_t po_bc_sad_workspace(uint64_t n, uint32_t dim);
 int po_launch_bc_sad_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,

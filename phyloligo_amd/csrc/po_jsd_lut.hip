@@ -54,13 +54,16 @@ __global__ __launch_bounds__(256) void prep_counts_kernel(const uint32_t* __rest
 
 // cls[b] = common word total of records [128b, 128b+128) (padding ignored), 0 if they differ, if one is
 // empty, or if any count in the matrix exceeds what the table covers.
+// The table identity needs sum_w count = total for every record (what count2freq guarantees); a caller-supplied
+// total that disagrees with its counts shows up as wsum = sum_w count/total != 1 and sends the block to the general kernel.
 __global__ __launch_bounds__(128) void classify_kernel(const unsigned long long* __restrict__ totals, uint64_t n,
                                                        const uint32_t* __restrict__ maxcount,
+                                                       const double* __restrict__ wsum,
                                                        unsigned long long* __restrict__ cls) {
     const uint64_t r = (uint64_t)blockIdx.x * 128 + threadIdx.x;
     const uint64_t first = (uint64_t)blockIdx.x * 128;
     const unsigned long long ref = totals[first];                     // first < n by construction of the grid
-    const bool ok = (r >= n) || (totals[r] == ref);
+    const bool ok = (r >= n) || (totals[r] == ref && fabs(wsum[r] - 1.0) < 1e-9);
     const int all = __syncthreads_and(ok ? 1 : 0);
     if (threadIdx.x == 0) cls[blockIdx.x] = (all && ref > 0 && 2u * *maxcount < (uint32_t)kLutEntries) ? ref : 0ull;
 }
@@ -201,7 +204,7 @@ size_t po_jsd_lut_workspace(uint64_t n, uint32_t dim) {
 
 // Builds Ct, the table and the tile classes in ws (layout as sized above); returns the class array.
 int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
-                           uint64_t npad, void* ws, const unsigned long long** cls_out) {
+                           uint64_t npad, const double* d_wsum, void* ws, const unsigned long long** cls_out) {
     uint8_t* base = static_cast<uint8_t*>(ws);
     uint32_t* ct = reinterpret_cast<uint32_t*>(base);
     base += po_round_up(dim, 8) * npad * sizeof(uint32_t);
@@ -216,7 +219,7 @@ int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t
     hipLaunchKernelGGL(lut_table_kernel, dim3(1), dim3(kLutEntries), 0, ctx->stream, lut);
     PO_CHECK_LAUNCH("lut_table_kernel");
     hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, ctx->stream,
-                       reinterpret_cast<const unsigned long long*>(d_totals), n, maxcount, cls);
+                       reinterpret_cast<const unsigned long long*>(d_totals), n, maxcount, d_wsum, cls);
     PO_CHECK_LAUNCH("classify_kernel");
     *cls_out = cls;
     return PO_OK;

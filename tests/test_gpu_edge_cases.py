@@ -131,3 +131,20 @@ def test_long_records_int8_overflow_and_table_limits(ctx):
         for metric in ("JSD", "Eucl", "BC"):
             np.testing.assert_allclose(ctx.pairwise(counts, totals, metric), po.pairwise_block(freq, metric),
                                        rtol=RTOL, atol=ATOL)
+
+
+def test_totals_that_disagree_with_counts(ctx):
+    """The C ABI takes totals separately.  Totals that are not the row sums of the counts (equal for all records,
+    so the equal-total fast paths are candidates) must still give metric(count/total) exactly as the general
+    kernels do: the table kernel's identity sum_w f = 1 does not hold and has to be refused on the device."""
+    from oracle import phyloligo_oracle as po
+    rng = np.random.default_rng(12)
+    counts = rng.integers(0, 30, size=(300, 256), dtype=np.uint32)
+    totals = np.full(300, 5000, dtype=np.uint64)                   # row sums are ~3700
+    freq = counts / totals[:, None].astype(np.float64)
+    for metric in ("JSD", "BC", "Eucl"):
+        got = ctx.pairwise(counts, totals, metric)
+        ref = ctx.pairwise(counts, totals, metric, table_path=False, rc_fold=False)
+        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-14)
+        want = po.pairwise_block(freq, metric)
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
