@@ -67,10 +67,10 @@ typedef enum po_dtype { PO_F64 = 0, PO_F32 = 1 } po_dtype;
                                   (what sklearn does for n_jobs>1); default mirrors j<i from i<j */
 
 #define PO_FLAG_NO_TABLE_PATH 2u /* general kernels only: no integer-sum table kernel for JSD record blocks with
-                                   equal word totals, no exact int8-MFMA kernel for Eucl profiles <= 127,
+                                   equal word totals, no exact int8-MFMA kernel for Eucl / SC,
                                    no packed-byte SAD kernel for BC, no int8-MFMA kernel for KT           */
 
-#define PO_FLAG_NO_RC_FOLD 4u /* JSD / BC: do not look for reverse-complement symmetric profiles.  By default
+#define PO_FLAG_NO_RC_FOLD 4u /* JSD / BC / KT: do not look for reverse-complement symmetric profiles.  By default
                                  the input is checked on the device (count[w] == count[rc(w)] for every record
                                  and word - what `-s both` with a palindromic pattern produces,
                                  bin/phyloligo.py:141) and, if it holds, the sums over words run over one word
@@ -93,7 +93,7 @@ typedef struct po_stats {
 #define PO_KERNEL_VALU_JSD 1u
 #define PO_KERNEL_VALU_BC 2u
 #define PO_KERNEL_MFMA_F64_GRAM 3u
-#define PO_KERNEL_MFMA_I8_GRAM 4u  /* exact int8 kernel when every count <= 127, else the float64 one */
+#define PO_KERNEL_MFMA_I8_GRAM 4u  /* exact int8 kernels (counts <= 16383; Spearman ranks, dim <= 8191), else the float64 one */
 #define PO_KERNEL_VALU_KT 5u
 #define PO_KERNEL_MFMA_I8_KT 8u /* Kendall tau as an int8-MFMA Gram over pair-sign vectors (dim <= 256) */
 #define PO_KERNEL_SAD_BC 7u    /* packed-byte SAD kernel (equal-total blocks) + general kernel for the rest */
