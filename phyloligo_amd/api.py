@@ -253,20 +253,49 @@ class Context:
 
 
 # ---- host formats -------------------------------------------------------------------------------
+class _Titles:
+    """Record titles of a FASTA file, decoded on demand (50 000 Python strings cost more than the parse)."""
+
+    def __init__(self, blob, bounds):
+        self._blob, self._bounds = blob, bounds
+
+    def __len__(self):
+        return len(self._bounds) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self._blob[int(self._bounds[i]):int(self._bounds[i + 1])].tobytes().decode("latin-1")
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+
 def fasta_index(data):
-    """bytes / numpy uint8 of a FASTA file -> (seq uint8[total], offsets uint64[n+1], titles list)."""
+    """bytes / numpy uint8 of a FASTA file -> (seq uint8[total], offsets uint64[n+1], titles sequence)."""
     lib = _lib.load()
     buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
     buf = np.ascontiguousarray(buf)
     nrec, nbytes = ctypes.c_uint64(), ctypes.c_uint64()
     check(lib.po_fasta_scan(_np_ptr(buf), buf.shape[0], ctypes.byref(nrec), ctypes.byref(nbytes)))
-    seq = np.zeros(nbytes.value, dtype=np.uint8)
+    seq = np.empty(nbytes.value, dtype=np.uint8)
     offsets = np.zeros(nrec.value + 1, dtype=np.uint64)
     tb = np.zeros(nrec.value, dtype=np.uint64)
     te = np.zeros(nrec.value, dtype=np.uint64)
     check(lib.po_fasta_extract(_np_ptr(buf), buf.shape[0], _np_ptr(seq), _np_ptr(offsets), _np_ptr(tb), _np_ptr(te)))
-    titles = [buf[int(b):int(e)].tobytes().decode("latin-1") for b, e in zip(tb, te)]
-    return seq, offsets, titles
+    # title bytes gathered into one blob (the file buffer may be a memmap that goes away)
+    lens = (te - tb).astype(np.int64)
+    bounds = np.zeros(nrec.value + 1, dtype=np.int64)
+    np.cumsum(lens, out=bounds[1:])
+    idx = np.repeat(tb.astype(np.int64) - bounds[:-1], lens) + np.arange(int(bounds[-1]), dtype=np.int64)
+    return seq, offsets, _Titles(np.asarray(buf[idx]) if idx.size else np.zeros(0, np.uint8), bounds)
 
 
 def write_mat_text(path, m, append=False):

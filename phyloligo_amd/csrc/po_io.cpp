@@ -33,14 +33,15 @@ inline bool is_py_space(uint8_t c) {  // bytes.rstrip() / str.rstrip() default s
     return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0x0b || c == 0x0c;
 }
 
-// Walks the records; with seq_out == NULL only counts.  Returns 0 or PO_EIO.
-int fasta_walk(const uint8_t* data, uint64_t len, uint8_t* seq_out, uint64_t* offsets_out, uint64_t* title_begin,
-               uint64_t* title_end, uint64_t* n_records, uint64_t* seq_bytes) {
-    uint64_t pos = 0, nrec = 0, nout = 0;
-    bool in_record = false;
-    while (pos < len) {
-        const uint8_t* nl = static_cast<const uint8_t*>(memchr(data + pos, '\n', len - pos));
-        const uint64_t line_end = nl ? (uint64_t)(nl - data) : len;   // exclusive, without the '\n'
+// Walks the lines of data[begin, end) (begin is a line start).  With seq_out == NULL only counts.
+// rec_base / out_base: records and sequence bytes that precede this segment.  Returns 0 or PO_EIO.
+int fasta_walk(const uint8_t* data, uint64_t begin, uint64_t end, bool in_record, uint64_t rec_base, uint64_t out_base,
+               uint8_t* seq_out, uint64_t* offsets_out, uint64_t* title_begin, uint64_t* title_end,
+               uint64_t* n_records, uint64_t* seq_bytes) {
+    uint64_t pos = begin, nrec = rec_base, nout = out_base;
+    while (pos < end) {
+        const uint8_t* nl = static_cast<const uint8_t*>(memchr(data + pos, '\n', end - pos));
+        const uint64_t line_end = nl ? (uint64_t)(nl - data) : end;   // exclusive, without the '\n'
         uint64_t e = line_end;
         while (e > pos && is_py_space(data[e - 1])) --e;              // rstrip
         if (data[pos] == '>' && line_end > pos) {
@@ -54,19 +55,77 @@ int fasta_walk(const uint8_t* data, uint64_t len, uint8_t* seq_out, uint64_t* of
                 po_set_error("FASTA input does not start with '>' (byte %llu)", (unsigned long long)pos);
                 return PO_EIO;
             }
-        } else {
+        } else if (seq_out) {
             for (uint64_t i = pos; i < e; ++i) {
                 const uint8_t c = data[i];
                 if (c == ' ' || c == '\r') continue;
-                if (seq_out) seq_out[nout] = c;
-                ++nout;
+                seq_out[nout++] = c;
             }
+        } else {
+            for (uint64_t i = pos; i < e; ++i) nout += (data[i] != ' ' && data[i] != '\r');
         }
-        pos = nl ? line_end + 1 : len;
+        pos = nl ? line_end + 1 : end;
     }
-    if (offsets_out) offsets_out[nrec] = nout;
-    if (n_records) *n_records = nrec;
-    if (seq_bytes) *seq_bytes = nout;
+    if (n_records) *n_records = nrec - rec_base;
+    if (seq_bytes) *seq_bytes = nout - out_base;
+    return PO_OK;
+}
+
+// The file is cut at line starts into one segment per host thread.  Only the text before the first record
+// depends on what came earlier (it must be blank), so that prelude is walked first, on its own; every later
+// segment starts inside a record.  Pass 1 counts records and sequence bytes per segment, a prefix sum places
+// them, pass 2 (extract only) writes.  Same result as one sequential walk.
+int fasta_parallel(const uint8_t* data, uint64_t len, uint8_t* seq_out, uint64_t* offsets_out, uint64_t* title_begin,
+                   uint64_t* title_end, uint64_t* n_records, uint64_t* seq_bytes) {
+    // prelude: up to the first line that starts with '>'
+    uint64_t first = 0;
+    while (first < len) {
+        if (data[first] == '>') break;
+        const uint8_t* nl = static_cast<const uint8_t*>(memchr(data + first, '\n', len - first));
+        if (!nl) { first = len; break; }
+        first = (uint64_t)(nl - data) + 1;
+    }
+    int rc = fasta_walk(data, 0, first, false, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+
+    unsigned hw = std::thread::hardware_concurrency();
+    uint64_t nseg = hw ? hw : 4;
+    if (nseg > 32) nseg = 32;
+    const uint64_t body = len - first;
+    if (body / (4u << 20) + 1 < nseg) nseg = body / (4u << 20) + 1;   // at least 4 MiB per thread
+    std::vector<uint64_t> cut(nseg + 1, len);
+    cut[0] = first;
+    for (uint64_t s = 1; s < nseg; ++s) {
+        uint64_t p = first + body / nseg * s;
+        if (p < cut[s - 1]) p = cut[s - 1];
+        const uint8_t* nl = p < len ? static_cast<const uint8_t*>(memchr(data + p, '\n', len - p)) : nullptr;
+        cut[s] = nl ? (uint64_t)(nl - data) + 1 : len;
+    }
+    std::vector<uint64_t> nrec(nseg, 0), nout(nseg, 0);
+    std::vector<int> rcs(nseg, PO_OK);
+    auto run = [&](const std::function<void(uint64_t)>& body_fn) {
+        if (nseg == 1) { body_fn(0); return; }
+        std::vector<std::thread> th;
+        for (uint64_t s = 0; s < nseg; ++s) th.emplace_back(body_fn, s);
+        for (auto& t : th) t.join();
+    };
+    run([&](uint64_t s) {
+        rcs[s] = fasta_walk(data, cut[s], cut[s + 1], true, 0, 0, nullptr, nullptr, nullptr, nullptr, &nrec[s], &nout[s]);
+    });
+    uint64_t rec_total = 0, out_total = 0;
+    std::vector<uint64_t> rec_base(nseg), out_base(nseg);
+    for (uint64_t s = 0; s < nseg; ++s) {
+        rec_base[s] = rec_total; out_base[s] = out_total;
+        rec_total += nrec[s]; out_total += nout[s];
+    }
+    if (n_records) *n_records = rec_total;
+    if (seq_bytes) *seq_bytes = out_total;
+    if (!offsets_out) return PO_OK;
+    run([&](uint64_t s) {
+        rcs[s] = fasta_walk(data, cut[s], cut[s + 1], true, rec_base[s], out_base[s], seq_out, offsets_out, title_begin,
+                            title_end, nullptr, nullptr);
+    });
+    offsets_out[rec_total] = out_total;
     return PO_OK;
 }
 
@@ -77,7 +136,7 @@ extern "C" int po_fasta_scan(const uint8_t* data, uint64_t len, uint64_t* n_reco
         po_set_error("po_fasta_scan: NULL argument");
         return PO_EINVAL;
     }
-    return fasta_walk(data, len, nullptr, nullptr, nullptr, nullptr, n_records, seq_bytes);
+    return fasta_parallel(data, len, nullptr, nullptr, nullptr, nullptr, n_records, seq_bytes);
 }
 
 extern "C" int po_fasta_extract(const uint8_t* data, uint64_t len, uint8_t* seq_out, uint64_t* offsets_out,
@@ -86,8 +145,7 @@ extern "C" int po_fasta_extract(const uint8_t* data, uint64_t len, uint8_t* seq_
         po_set_error("po_fasta_extract: NULL argument");
         return PO_EINVAL;
     }
-    uint8_t dummy;
-    return fasta_walk(data, len, seq_out ? seq_out : &dummy, offsets_out, title_begin, title_end, nullptr, nullptr);
+    return fasta_parallel(data, len, seq_out, offsets_out, title_begin, title_end, nullptr, nullptr);
 }
 
 // "%.18e" of one value into p, numpy spelling of non-finite values; returns the new end.

@@ -138,3 +138,31 @@ def test_kount_window_rules_match_reference(golden_dir):
     p = kount.get_cmd(["-i", "x.fa"])
     assert (p.k, p.pattern, p.windows_size, p.windows_step, p.dist, p.strand, p.n_max_freq_in_windows) == \
         (4, None, 5000, 500, "JSD", "both", 0.4)
+
+
+def test_fasta_parallel_segments_equal_sequential_semantics():
+    """A file large enough to be cut into several host-thread segments (>= 4 MiB each): ragged line lengths, CRLF,
+    blank lines, spaces, '>' inside sequence lines, empty records - against the oracle's line-by-line parser."""
+    rng = np.random.default_rng(99)
+    alphabet = np.frombuffer(b"ACGTacgtNn> \t", dtype=np.uint8)
+    probs = np.array([22, 22, 22, 22, 2, 2, 2, 2, 1, 1, 0.5, 1, 0.5])
+    probs = probs / probs.sum()
+    parts = [b"\n  \n"]                                            # blank prelude
+    for r in range(6000):
+        parts.append(b">rec%d some description %d \r\n" % (r, r * 7))
+        for _ in range(int(rng.integers(0, 60))):
+            line = alphabet[rng.choice(len(alphabet), size=int(rng.integers(0, 120)), p=probs)].tobytes()
+            if line.startswith(b">"):
+                line = b"A" + line
+            parts.append(line + (b"\r\n" if r % 3 == 0 else b"\n"))
+        if r % 500 == 0:
+            parts.append(b"\n\n")
+    data = b"".join(parts)
+    assert len(data) > 10 << 20                                   # >= 3 segments of >= 4 MiB
+    titles, seqs = po.parse_fasta(data)
+    seq, offsets, got_titles = pa.fasta_index(data)
+    assert len(got_titles) == len(titles) == 6000
+    assert got_titles[0] == titles[0] and got_titles[5999] == titles[5999] and got_titles[1234:1237] == titles[1234:1237]
+    assert int(offsets[-1]) == sum(len(s) for s in seqs) == seq.shape[0]
+    assert seq.tobytes() == b"".join(seqs)
+    assert np.array_equal(np.diff(offsets.astype(np.int64)), np.array([len(s) for s in seqs]))
