@@ -2,6 +2,9 @@
 // host-pointer convenience forms, and the dispatch of a pairwise request onto the tile kernels.
 #include "po_internal.h"
 
+#include <thread>
+#include <vector>
+
 #include <stdarg.h>
 #include <stdlib.h>
 
@@ -87,6 +90,8 @@ extern "C" void po_ctx_destroy(po_ctx* ctx) {
     buf_free(&ctx->ws_fold);
     buf_free(&ctx->ws_fold_src);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
     for (int i = 0; i < 4; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;
@@ -662,6 +667,47 @@ extern "C" int po_pairwise_blocks_dev(po_ctx* ctx, const uint32_t* d_counts, con
                          n_blocks, flags, stats);
 }
 
+// Device rows -> pageable host rows through two pinned staging buffers: the DMA of chunk c+1 runs while host
+// threads copy chunk c into the caller's memory.  (A plain hipMemcpy to pageable memory stages through one
+// runtime thread: ~11 GB/s measured on the gpurun box against ~25 GB/s this way.)
+static int copy_rows_to_host(po_ctx* ctx, const uint8_t* d_src, size_t src_pitch, size_t row_bytes, uint64_t rows,
+                             uint8_t* dst, size_t dst_pitch) {
+    const size_t kStage = 32u << 20;
+    if (rows == 0 || row_bytes == 0) return PO_OK;
+    if (rows * row_bytes < (64u << 20) || row_bytes > kStage) {      // small result (or absurdly long rows): one plain copy
+        PO_HIP(hipMemcpy2DAsync(dst, dst_pitch, d_src, src_pitch, row_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
+        PO_HIP(hipStreamSynchronize(ctx->stream));
+        return PO_OK;
+    }
+    if (!ctx->h_stage[0]) {
+        PO_HIP(hipHostMalloc(&ctx->h_stage[0], kStage, hipHostMallocDefault));
+        PO_HIP(hipHostMalloc(&ctx->h_stage[1], kStage, hipHostMallocDefault));
+    }
+    const uint64_t rows_per = kStage / row_bytes;
+    const uint64_t n_chunks = (rows + rows_per - 1) / rows_per;
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_thr = hw ? (hw > 8 ? 8 : hw) : 4;
+    auto issue = [&](uint64_t c) -> hipError_t {
+        const uint64_t r0 = c * rows_per, nr = (rows - r0 < rows_per) ? rows - r0 : rows_per;
+        return hipMemcpy2DAsync(ctx->h_stage[c & 1], row_bytes, d_src + r0 * src_pitch, src_pitch, row_bytes, nr,
+                                hipMemcpyDeviceToHost, ctx->stream);
+    };
+    PO_HIP(issue(0));
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        PO_HIP(hipStreamSynchronize(ctx->stream));                    // chunk c is in its staging buffer
+        if (c + 1 < n_chunks) PO_HIP(issue(c + 1));                   // next DMA overlaps the host copies below
+        const uint64_t r0 = c * rows_per, nr = (rows - r0 < rows_per) ? rows - r0 : rows_per;
+        const uint8_t* src = static_cast<const uint8_t*>(ctx->h_stage[c & 1]);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < n_thr; ++t)
+            th.emplace_back([=]() {
+                for (uint64_t r = t; r < nr; r += n_thr) memcpy(dst + (r0 + r) * dst_pitch, src + r * row_bytes, row_bytes);
+            });
+        for (auto& x : th) x.join();
+    }
+    return PO_OK;
+}
+
 // host-pointer forms: stage in ws_io, run the device form, copy the rows back
 static int pairwise_host(po_ctx* ctx, const char* who, const uint32_t* counts, const uint64_t* totals,
                          const double* freq, uint64_t n, uint32_t dim, int metric, uint64_t row_begin,
@@ -704,9 +750,7 @@ static int pairwise_host(po_ctx* ctx, const char* who, const uint32_t* counts, c
                            flags, stats);
     }
     if (rc) return rc;
-    PO_HIP(hipMemcpy2DAsync(out, ld_out * esz, d_out, n * esz, n * esz, rows, hipMemcpyDeviceToHost, ctx->stream));
-    PO_HIP(hipStreamSynchronize(ctx->stream));
-    return PO_OK;
+    return copy_rows_to_host(ctx, static_cast<const uint8_t*>(d_out), n * esz, n * esz, rows, static_cast<uint8_t*>(out), ld_out * esz);
 }
 
 extern "C" int po_pairwise(po_ctx* ctx, const uint32_t* counts, const uint64_t* totals, uint64_t n, uint32_t dim,

@@ -59,6 +59,7 @@ struct po_ctx {
     po_buf ws_fold_src;                // source word of every folded column, for (fold_dim, fold_gran)
     uint32_t fold_dim = 0, fold_gran = 0, fold_dim_f = 0, fold_dbl_at = 0;
     uint32_t* h_flag = nullptr;        // pinned host word for the fold decision
+    void* h_stage[2] = {nullptr, nullptr};   // pinned staging buffers of the host-pointer entry points (device -> host rows)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
