@@ -19,43 +19,97 @@ constexpr int PT = 16;            // 16 x 16 record pairs per workgroup, one pai
 constexpr int CH = 128;           // words per staged chunk
 constexpr int kRow = CH + 1;      // +1: rows of a chunk start in different banks
 
+constexpr uint32_t kValueBins = 8192;   // counts below this take the histogram path of row_order_kernel (64 KiB of LDS)
+
 // One workgroup per record, input row major (uint32 counts or float64 frequencies).
 //   rt[d][npad]      centred average rank of word d:  #less + (#equal - D)/2
 //   lessrank[r][d]   #less (an integer with the order and ties of the input)
 //   r2[r][d]         2 #less + #equal - D = twice the centred average rank, an exact integer (po_gram_i8.hip)
 //   rowstat[3][r]    number of word pairs tied in the record
-template <typename T>
+// Integer counts below kValueBins (decided per record, on the device): #less and #equal come from the
+// histogram of the record's count VALUES and its prefix sum - O(D + max count) instead of the O(D^2)
+// all-pairs comparison that float64 input (and very long records) still use.
+template <typename T, bool COUNTS>
 __global__ __launch_bounds__(kThreads) void row_order_kernel(const T* __restrict__ rows, uint64_t n, uint32_t dim,
                                                              uint64_t npad, double* __restrict__ rt,
                                                              uint32_t* __restrict__ lessrank, int32_t* __restrict__ r2,
                                                              double* __restrict__ rowstat) {
+    extern __shared__ __align__(16) unsigned char dyn[];                // COUNTS: hist[kValueBins] | pref[kValueBins]
     __shared__ T chunk[2048];
     __shared__ unsigned long long tied;
+    __shared__ uint32_t red[kThreads];
     const uint64_t r = blockIdx.x;
     const uint32_t t = threadIdx.x;
     if (t == 0) tied = 0;
     const T* row = rows + r * dim;
     unsigned long long my_tied = 0;
-    for (uint32_t base = 0; base < dim; base += kThreads) {          // words owned by lanes this round
-        const uint32_t d = base + t;
-        const T x = (d < dim) ? row[d] : T(0);
-        uint32_t less = 0, equal = 0;
-        for (uint32_t c0 = 0; c0 < dim; c0 += 2048) {
-            const uint32_t len = min(2048u, dim - c0);
+    auto emit = [&](uint32_t d, uint32_t less, uint32_t equal) {
+        if (rt) rt[(uint64_t)d * npad + r] = (double)less + 0.5 * ((double)equal - (double)dim);
+        if (lessrank) lessrank[r * dim + d] = less;
+        if (r2) r2[r * dim + d] = (int32_t)(2u * less + equal) - (int32_t)dim;
+        my_tied += equal - 1;                                        // ordered tied partners of word d
+    };
+
+    bool by_histogram = false;
+    if (COUNTS) {
+        uint32_t* hist = reinterpret_cast<uint32_t*>(dyn);
+        uint32_t* pref = hist + kValueBins;
+        uint32_t mx = 0;
+        for (uint32_t d = t; d < dim; d += kThreads) mx = max(mx, (uint32_t)row[d]);
+        red[t] = mx;
+        __syncthreads();
+        for (uint32_t s = kThreads / 2; s > 0; s >>= 1) {
+            if (t < s) red[t] = max(red[t], red[t + s]);
             __syncthreads();
-            for (uint32_t i = t; i < len; i += kThreads) chunk[i] = row[c0 + i];
+        }
+        const uint32_t vmax = red[0];                                // uniform over the workgroup
+        __syncthreads();
+        by_histogram = vmax < kValueBins;
+        if (by_histogram) {
+            const uint32_t nv = vmax + 1;
+            for (uint32_t v = t; v < nv; v += kThreads) hist[v] = 0;
             __syncthreads();
-            for (uint32_t i = 0; i < len; ++i) {
-                const T y = chunk[i];
-                less += (y < x);
-                equal += (y == x);
+            for (uint32_t d = t; d < dim; d += kThreads) atomicAdd(&hist[(uint32_t)row[d]], 1u);
+            __syncthreads();
+            // exclusive prefix sum of hist[0..nv): contiguous segment per lane, scan of the 256 segment sums
+            const uint32_t seg = (nv + kThreads - 1) / kThreads;
+            const uint32_t v0 = min(t * seg, nv), v1 = min(v0 + seg, nv);
+            uint32_t ssum = 0;
+            for (uint32_t v = v0; v < v1; ++v) ssum += hist[v];
+            red[t] = ssum;
+            __syncthreads();
+            for (uint32_t dlt = 1; dlt < kThreads; dlt <<= 1) {
+                const uint32_t u = (t >= dlt) ? red[t - dlt] : 0u;
+                __syncthreads();
+                red[t] += u;
+                __syncthreads();
+            }
+            uint32_t run = red[t] - ssum;
+            for (uint32_t v = v0; v < v1; ++v) { pref[v] = run; run += hist[v]; }
+            __syncthreads();
+            for (uint32_t d = t; d < dim; d += kThreads) {
+                const uint32_t v = (uint32_t)row[d];
+                emit(d, pref[v], hist[v]);
             }
         }
-        if (d < dim) {
-            if (rt) rt[(uint64_t)d * npad + r] = (double)less + 0.5 * ((double)equal - (double)dim);
-            if (lessrank) lessrank[r * dim + d] = less;
-            if (r2) r2[r * dim + d] = (int32_t)(2u * less + equal) - (int32_t)dim;
-            my_tied += equal - 1;                                    // ordered tied partners of word d
+    }
+    if (!by_histogram) {
+        for (uint32_t base = 0; base < dim; base += kThreads) {          // words owned by lanes this round
+            const uint32_t d = base + t;
+            const T x = (d < dim) ? row[d] : T(0);
+            uint32_t less = 0, equal = 0;
+            for (uint32_t c0 = 0; c0 < dim; c0 += 2048) {
+                const uint32_t len = min(2048u, dim - c0);
+                __syncthreads();
+                for (uint32_t i = t; i < len; i += kThreads) chunk[i] = row[c0 + i];
+                __syncthreads();
+                for (uint32_t i = 0; i < len; ++i) {
+                    const T y = chunk[i];
+                    less += (y < x);
+                    equal += (y == x);
+                }
+            }
+            if (d < dim) emit(d, less, equal);
         }
     }
     for (int o = 32; o > 0; o >>= 1) my_tied += __shfl_down(my_tied, o, 64);
@@ -142,12 +196,16 @@ int po_launch_ranks(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq,
         hipLaunchKernelGGL(zero_pad_kernel, dim3(256), dim3(kThreads), 0, ctx->stream, d_rt, n, dim, npad);
         PO_CHECK_LAUNCH("zero_pad_kernel");
     }
-    if (d_counts)
-        hipLaunchKernelGGL(row_order_kernel<uint32_t>, dim3((uint32_t)n), dim3(kThreads), 0, ctx->stream, d_counts, n, dim,
+    if (d_counts) {
+        auto k = row_order_kernel<uint32_t, true>;
+        const size_t shmem = 2 * kValueBins * sizeof(uint32_t);
+        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(k, dim3((uint32_t)n), dim3(kThreads), shmem, ctx->stream, d_counts, n, dim, npad, d_rt, d_lessrank,
+                           d_r2, d_rowstat);
+    } else {
+        hipLaunchKernelGGL((row_order_kernel<double, false>), dim3((uint32_t)n), dim3(kThreads), 0, ctx->stream, d_freq, n, dim,
                            npad, d_rt, d_lessrank, d_r2, d_rowstat);
-    else
-        hipLaunchKernelGGL(row_order_kernel<double>, dim3((uint32_t)n), dim3(kThreads), 0, ctx->stream, d_freq, n, dim,
-                           npad, d_rt, d_lessrank, d_r2, d_rowstat);
+    }
     PO_CHECK_LAUNCH("row_order_kernel");
     return PO_OK;
 }

@@ -81,3 +81,19 @@ def test_spearman_dimension_beyond_two_digits_uses_float64(ctx):
     got, st = ctx.pairwise_freq(freq, "SC", want_stats=True)
     assert st["kernel_id"] == F64
     np.testing.assert_allclose(got, oracle.pairwise_block(freq, "SC"), rtol=RTOL, atol=ATOL)
+
+
+def test_rank_statistics_histogram_and_comparison_paths_agree(ctx):
+    """row_order_kernel ranks integer counts below 8192 through a value histogram and everything else (larger
+    counts, float64 input) by all-pairs comparison: same ranks, same ties, so KT and SC must agree bit for bit."""
+    rng = np.random.default_rng(77)
+    counts = rng.integers(0, 40, size=(130, 256), dtype=np.uint32)
+    counts[4, 9] = 8191                                  # still the histogram path
+    counts[5, 9] = 8192                                  # this record alone falls back to comparisons
+    counts[6] = 20000 + rng.integers(0, 3, size=256)     # many ties among large values
+    totals = counts.sum(1).astype(np.uint64)
+    freq = ctx.frequencies(counts, totals)
+    for metric in ("KT", "SC"):
+        from_counts = ctx.pairwise(counts, totals, metric)
+        from_freq = ctx.pairwise_freq(freq, metric)      # float64 input: comparison path for every record
+        assert np.array_equal(from_counts, from_freq, equal_nan=True), metric

@@ -1,5 +1,5 @@
 """Full matrix at a size beyond the BASELINE configs (default N = 120 000: 115 GB of float64 on one GPU),
-spot-checked against the oracle on a few rows and for symmetry.  usage: large_n_check.py [N] [metric]"""
+spot-checked against the oracle on a few rows and for symmetry.  usage: large_n_check.py [N] [metric] [pattern]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
@@ -9,10 +9,11 @@ from oracle import phyloligo_oracle as oracle
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 120000
 metric = sys.argv[2] if len(sys.argv) > 2 else "JSD"
+pattern = sys.argv[3] if len(sys.argv) > 3 else "1111"
 ctx = pa.Context(0)
 seq, off = synthetic.contig_bytes(n, 2000, seed=7)
 dseq = torch.from_numpy(seq).cuda(); doff = torch.from_numpy(off.astype(np.int64)).cuda()
-counts, totals = ctx.count_profiles(dseq, doff, "1111", "both")
+counts, totals = ctx.count_profiles(dseq, doff, pattern, "both")
 out = torch.empty((n, n), dtype=torch.float64, device="cuda")
 torch.cuda.synchronize(); t = time.perf_counter()
 _, st = ctx.pairwise(counts, totals, metric, out=out, want_stats=True)
@@ -21,7 +22,6 @@ print("N=%d %s: %.1f ms (kernel %.1f), %.3e pairs/s, kernel id %d, folded %s" % 
     n, metric, st["total_ms"], st["kernel_ms"], n * (n - 1) / 2 / (st["total_ms"] * 1e-3), st["kernel_id"], st["rc_folded"]), flush=True)
 freq = oracle.counts_to_frequencies(counts.cpu().numpy().astype(np.int64), totals.cpu().numpy())
 rows = [0, n // 3 + 17, n - 1]
-want = oracle.pairwise_block(freq[:], metric, 0, 0) if False else None
 for r in rows:
     w = oracle.pairwise_block(np.vstack([freq[r:r + 1], freq]), metric, 0, 1)[0, 1:]
     g = out[r].cpu().numpy()
