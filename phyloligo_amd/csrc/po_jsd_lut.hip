@@ -6,12 +6,12 @@
 // h = (a+b)/2 has h_w = (ca_w + cb_w) / 2n, so
 //     S = sum_w (a_w+b_w) ln(a_w+b_w) = (1/n) sum_w T[ca_w + cb_w] - 2 ln n,   T[x] = x ln x,
 // and the per-word, per-pair work collapses from a float64 logarithm to ONE integer add, ONE LDS read
-// and ONE float64 add.  T[x] for x = 0..127 sits in LDS replicated 32x (entry x, copy c at byte
+// and ONE float64 add.  T[x] for x = 0..255 sits in LDS replicated 32x (entry x, copy c at byte
 // x*256 + c*8) so that the per-lane lookups of a wave never conflict; counts are staged pre-shifted by 8
 // bits, so a lookup address is a single v_add3_u32.
 //
 // Eligibility is decided per tile on the device: classify_kernel marks each block of 128 records with its
-// common total (0 = mixed / empty / a count above 63); a tile (I,J) takes this path iff both classes are
+// common total (0 = mixed / empty / a count above 127); a tile (I,J) takes this path iff both classes are
 // equal and non-zero, every other tile is left to valu_tile_kernel<JSD>, which skips the marked ones.
 #include "po_tiles.h"
 
@@ -21,7 +21,7 @@ namespace {
 
 constexpr int TM = 128, TN = 128;
 constexpr int KC = 8;
-constexpr int kLutEntries = 128;                       // sums 0..127  -> counts up to 63
+constexpr int kLutEntries = 256;                       // sums 0..255  -> counts up to 127 (fixed-length contigs up to ~10 kb at k=4)
 constexpr int kLutBytes = kLutEntries * 256;           // 32 copies x 8 B per entry
 constexpr int kStageWords = KC * (TM + TN);            // uint32 per buffer
 constexpr double LN2 = 0.693147180559945309417232121458;
@@ -239,6 +239,10 @@ int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, cons
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
     const size_t shmem = kLutBytes + 2 * kStageWords * sizeof(uint32_t);
     static const int rpt = getenv("PO_LUT_RPT") ? atoi(getenv("PO_LUT_RPT")) : 4;
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jsd_lut_tile_kernel<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jsd_lut_tile_kernel<float, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jsd_lut_tile_kernel<double, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jsd_lut_tile_kernel<double, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     if (a.out_f32 && rpt == 4)
         hipLaunchKernelGGL((jsd_lut_tile_kernel<float, 4>), dim3((uint32_t)nblocks), dim3(512), shmem, ctx->stream, a, ct, lut, cls);
     else if (a.out_f32)

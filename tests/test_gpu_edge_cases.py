@@ -148,3 +148,18 @@ def test_totals_that_disagree_with_counts(ctx):
         np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-14)
         want = po.pairwise_block(freq, metric)
         np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+
+
+def test_jsd_table_kernel_covers_counts_up_to_127(ctx):
+    """5 kb fixed-length contigs at k=4: counts reach ~70, word sums ~140 - inside the 256-entry table."""
+    from oracle import phyloligo_oracle as po
+    from phyloligo_amd import synthetic
+    seq, off = synthetic.contig_bytes(384, 5000, seed=3)
+    counts, totals = ctx.count_profiles(seq, off, "1111", "both")
+    assert 63 < counts.max() <= 127 and totals.min() == totals.max()
+    table = ctx.pairwise(counts, totals, "JSD")
+    general = ctx.pairwise(counts, totals, "JSD", table_path=False)
+    np.testing.assert_allclose(table, general, rtol=1e-9, atol=1e-13)
+    assert not np.array_equal(table, general)                    # two different kernels did run
+    freq = po.counts_to_frequencies(counts.astype(np.int64), totals.astype(np.int64))
+    np.testing.assert_allclose(table, po.pairwise_block(freq, "JSD"), rtol=RTOL, atol=ATOL)
