@@ -184,7 +184,7 @@ def test_jsd_equal_total_table_path_and_mixed_tiles(ctx):
 
 
 @pytest.mark.parametrize("world", [2, 3, 4])
-@pytest.mark.parametrize("metric", ["JSD", "Eucl", "BC", "KT"])
+@pytest.mark.parametrize("metric", ["JSD", "Eucl", "BC", "KT", "SC"])
 def test_tournament_blocks_virtual_ranks(ctx, metric, world):
     """The multi-GPU work lists, run rank after rank on one GPU through po_pairwise_blocks_dev: the
     assembled slabs (after the mirror placement that complete_rows does over RCCL) equal the
