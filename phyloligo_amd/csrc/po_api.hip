@@ -463,9 +463,10 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     // ---- strand-symmetric profiles: one word per reverse-complement orbit (JSD, BC; po_fold.hip) ----
     uint32_t dbl_at = PO_NO_DOUBLING;
     bool folded = false;
+    uint32_t fold_flags = 0xFFFFFFFFu;     // all set = unknown: launch every candidate kernel
     if ((metric == PO_JSD || metric == PO_BC) && !(flags & PO_FLAG_NO_RC_FOLD)) {
         uint32_t dim_f = 0, at = PO_NO_DOUBLING;
-        rc = po_rc_fold(ctx, d_counts, d_freq, n, dim, metric == PO_BC ? 32u : 8u, &folded, &dim_f, &at);
+        rc = po_rc_fold(ctx, d_counts, d_freq, d_totals, n, dim, metric == PO_BC ? 32u : 8u, &folded, &dim_f, &at, &fold_flags);
         if (rc) return rc;
         if (folded) {
             if (d_counts) d_counts = static_cast<const uint32_t*>(ctx->ws_fold.p);
@@ -516,7 +517,7 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         const uint32_t* fold_src = nullptr;
         if (!(flags & PO_FLAG_NO_RC_FOLD) && selfs != 0xFFFFFFFFu && po_kt_mfma_fold_supported(dim, selfs)) {
             uint32_t dim_f = 0, at = 0;
-            rc = po_rc_fold(ctx, d_counts, d_freq, n, dim, PO_FOLD_SELFS_FIRST, &folded, &dim_f, &at);
+            rc = po_rc_fold(ctx, d_counts, d_freq, nullptr, n, dim, PO_FOLD_SELFS_FIRST, &folded, &dim_f, &at, nullptr);
             if (rc) return rc;
             if (folded) fold_src = static_cast<const uint32_t*>(ctx->ws_fold_src.p);
         }
@@ -570,7 +571,8 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
                     rc = po_launch_jsd_lut_tiles(ctx, a, n, ctx->ws_aux.p, &tiles);
                     if (rc) return rc;
                 }
-                rc = po_launch_valu_tiles(ctx, PO_JSD, a, cls, cls ? nullptr : &tiles);
+                // the fold pass may already have established that every record block takes the table kernel
+                if (!(cls && !(fold_flags & PO_FOLD_NOT_ALL_TABLE))) rc = po_launch_valu_tiles(ctx, PO_JSD, a, cls, cls ? nullptr : &tiles);
                 kid = cls ? PO_KERNEL_LUT_JSD : PO_KERNEL_VALU_JSD;
                 break;
             case PO_BC:
@@ -578,7 +580,7 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
                     rc = po_launch_bc_sad_tiles(ctx, a, ctx->ws_aux.p, &tiles);
                     if (rc) return rc;
                 }
-                rc = po_launch_valu_tiles(ctx, PO_BC, a, cls, cls ? nullptr : &tiles);
+                if (!(cls && !(fold_flags & PO_FOLD_NOT_ALL_SAD))) rc = po_launch_valu_tiles(ctx, PO_BC, a, cls, cls ? nullptr : &tiles);
                 kid = cls ? PO_KERNEL_SAD_BC : PO_KERNEL_VALU_BC;
                 break;
             case PO_EUCL:

@@ -1,4 +1,4 @@
-// Reverse-complement folding of strand-symmetric profiles (stage 2, JSD and Bray-Curtis).
+// Reverse-complement folding of strand-symmetric profiles (stage 2: JSD, Bray-Curtis, Kendall).
 //
 // Under `-s both` the reference counts the words of  seq + revcomp(seq)  (select_strand,
 // /root/reference/phylopackage/bin/phyloligo.py:124-149, :141).  That string is its own reverse
@@ -35,9 +35,13 @@ __device__ __host__ inline uint32_t rc_word(uint32_t w, uint32_t k) {
 template <typename T>
 __global__ __launch_bounds__(256) void rc_fold_kernel(const T* __restrict__ in, uint64_t n, uint32_t dim, uint32_t k,
                                                       const uint32_t* __restrict__ src, uint32_t dim_f, uint32_t rpb,
-                                                      T* __restrict__ out, uint32_t* __restrict__ asym) {
+                                                      T* __restrict__ out, uint32_t* __restrict__ asym,
+                                                      const unsigned long long* __restrict__ totals) {
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ unsigned long long sum_s[16];
+    __shared__ uint32_t max_s[16];
     T* rec = reinterpret_cast<T*>(smem);
+    if (threadIdx.x < 16) { sum_s[threadIdx.x] = 0; max_s[threadIdx.x] = 0; }
     const uint64_t row0 = (uint64_t)blockIdx.x * rpb;
     const uint32_t rows = (uint32_t)min((uint64_t)rpb, n - row0);
     const T* x = in + row0 * dim;
@@ -55,14 +59,42 @@ __global__ __launch_bounds__(256) void rc_fold_kernel(const T* __restrict__ in, 
         }
         y[e] = v;
     }
-    if (!sym) *asym = 1u;                                   // benign race: every writer stores the same value
+    if (!sym) atomicOr(asym, PO_FOLD_ASYM);
+    // integer counts: can every 128-record block take the equal-total fast path (po_jsd_lut.hip / po_bc_sad.hip)?
+    // If so the host need not launch the general tile kernel at all.  Same conditions as the classify kernels.
+    if (sizeof(T) == 4 && totals != nullptr) {
+        const uint32_t tpr = 256 / rpb;                     // threads per record (rpb is a power of two <= 16)
+        const uint32_t r = threadIdx.x / tpr, j = threadIdx.x % tpr;
+        if (r < rows) {
+            unsigned long long sum = 0;
+            uint32_t mx = 0;
+            for (uint32_t w = j; w < dim; w += tpr) {
+                const uint32_t v = (uint32_t)rec[r * dim + w];
+                sum += v;
+                mx = max(mx, v);
+            }
+            atomicAdd(&sum_s[r], sum);
+            atomicMax(&max_s[r], mx);
+        }
+        __syncthreads();
+        if (j == 0 && r < rows) {
+            const uint64_t row = row0 + r;
+            const unsigned long long tot = totals[row], ref = totals[row & ~(uint64_t)127];
+            const bool common = tot > 0 && tot == ref;
+            uint32_t bits = 0;
+            if (!(common && sum_s[r] == tot && max_s[r] <= 127u)) bits |= PO_FOLD_NOT_ALL_TABLE;
+            if (!(common && max_s[r] <= 255u)) bits |= PO_FOLD_NOT_ALL_SAD;
+            if (bits) atomicOr(asym, bits);
+        }
+    }
 }
 
 // rows too long for LDS (dim > 8192 words): one wave per record, partner reads from global memory
 template <typename T>
 __global__ __launch_bounds__(256) void rc_fold_long_kernel(const T* __restrict__ in, uint64_t n, uint32_t dim, uint32_t k,
                                                            const uint32_t* __restrict__ src, uint32_t dim_f,
-                                                           T* __restrict__ out, uint32_t* __restrict__ asym) {
+                                                           T* __restrict__ out, uint32_t* __restrict__ asym,
+                                                           const unsigned long long* __restrict__ totals) {
     const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     if (row >= n) return;
@@ -78,20 +110,41 @@ __global__ __launch_bounds__(256) void rc_fold_long_kernel(const T* __restrict__
         }
         y[d] = v;
     }
-    if (!sym) *asym = 1u;
+    if (!sym) atomicOr(asym, PO_FOLD_ASYM);
+    if (sizeof(T) == 4 && totals != nullptr) {              // see rc_fold_kernel
+        unsigned long long sum = 0;
+        uint32_t mx = 0;
+        for (uint32_t w = lane; w < dim; w += 64) {
+            const uint32_t v = (uint32_t)x[w];
+            sum += v;
+            mx = max(mx, v);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            sum += __shfl_down(sum, o, 64);
+            mx = max(mx, (uint32_t)__shfl_down(mx, o, 64));
+        }
+        if (lane == 0) {
+            const unsigned long long tot = totals[row], ref = totals[row & ~(uint64_t)127];
+            const bool common = tot > 0 && tot == ref;
+            uint32_t bits = 0;
+            if (!(common && sum == tot && mx <= 127u)) bits |= PO_FOLD_NOT_ALL_TABLE;
+            if (!(common && mx <= 255u)) bits |= PO_FOLD_NOT_ALL_SAD;
+            if (bits) atomicOr(asym, bits);
+        }
+    }
 }
 
 template <typename T>
 int launch_fold(po_ctx* ctx, const T* in, uint64_t n, uint32_t dim, uint32_t k, const uint32_t* src, uint32_t dim_f,
-                T* out, uint32_t* asym) {
+                T* out, uint32_t* asym, const unsigned long long* totals) {
     const size_t row_bytes = (size_t)dim * sizeof(T);
     if (row_bytes <= 32768) {
         const uint32_t rpb = (uint32_t)(32768 / row_bytes > 16 ? 16 : 32768 / row_bytes);
         hipLaunchKernelGGL(rc_fold_kernel<T>, dim3((uint32_t)((n + rpb - 1) / rpb)), dim3(256), rpb * row_bytes, ctx->stream,
-                           in, n, dim, k, src, dim_f, rpb, out, asym);
+                           in, n, dim, k, src, dim_f, rpb, out, asym, totals);
     } else {
         hipLaunchKernelGGL(rc_fold_long_kernel<T>, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, ctx->stream, in, n, dim, k,
-                           src, dim_f, out, asym);
+                           src, dim_f, out, asym, totals);
     }
     PO_CHECK_LAUNCH("rc_fold_kernel");
     return PO_OK;
@@ -157,9 +210,13 @@ uint32_t po_fold_selfs(uint32_t dim) {
 // symmetric.  On return *folded tells whether ws_fold holds an [n][*dim_f] matrix to use instead of the input.
 // Costs one pass over the input and one 4-byte device-to-host read (the only host synchronisation of
 // the pairwise entry points; PO_FLAG_NO_RC_FOLD skips it).
-int po_rc_fold(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint64_t n, uint32_t dim, uint32_t gran,
-               bool* folded, uint32_t* dim_f, uint32_t* dbl_at) {
+// d_totals (may be NULL) and *flags_out (may be NULL): the same pass also tells whether every 128-record block of
+// integer counts qualifies for the equal-total fast paths (PO_FOLD_NOT_ALL_TABLE / PO_FOLD_NOT_ALL_SAD clear), so
+// that the caller can leave out the general kernel's launch.  *flags_out == 0xFFFFFFFF: nothing was checked.
+int po_rc_fold(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, const uint64_t* d_totals, uint64_t n,
+               uint32_t dim, uint32_t gran, bool* folded, uint32_t* dim_f, uint32_t* dbl_at, uint32_t* flags_out) {
     *folded = false;
+    if (flags_out) *flags_out = 0xFFFFFFFFu;
     int rc = fold_plan(ctx, dim, gran, dim_f, dbl_at);
     if (rc || *dim_f == 0 || n == 0) return rc;
     const size_t esz = d_counts ? sizeof(uint32_t) : sizeof(double);
@@ -171,11 +228,13 @@ int po_rc_fold(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint
     PO_HIP(hipMemsetAsync(asym, 0, sizeof(uint32_t), ctx->stream));
     const uint32_t k = log4_exact(dim);
     const uint32_t* src = static_cast<const uint32_t*>(ctx->ws_fold_src.p);
-    rc = d_counts ? launch_fold<uint32_t>(ctx, d_counts, n, dim, k, src, *dim_f, reinterpret_cast<uint32_t*>(base), asym)
-                  : launch_fold<double>(ctx, d_freq, n, dim, k, src, *dim_f, reinterpret_cast<double*>(base), asym);
+    const unsigned long long* tot = reinterpret_cast<const unsigned long long*>(d_totals);
+    rc = d_counts ? launch_fold<uint32_t>(ctx, d_counts, n, dim, k, src, *dim_f, reinterpret_cast<uint32_t*>(base), asym, tot)
+                  : launch_fold<double>(ctx, d_freq, n, dim, k, src, *dim_f, reinterpret_cast<double*>(base), asym, nullptr);
     if (rc) return rc;
     PO_HIP(hipMemcpyAsync(ctx->h_flag, asym, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     PO_HIP(hipStreamSynchronize(ctx->stream));
-    *folded = (*ctx->h_flag == 0u);
+    *folded = (*ctx->h_flag & PO_FOLD_ASYM) == 0u;
+    if (flags_out && d_counts && d_totals) *flags_out = *ctx->h_flag;
     return PO_OK;
 }

@@ -126,8 +126,11 @@ struct po_tile_args {
 #define PO_FOLD_SELFS_FIRST 0xFFFFu    // `gran` value of po_rc_fold selecting the Kendall layout [self-paired | representatives]
 // Reverse-complement folding of strand-symmetric inputs (JSD, BC); see po_fold.hip
 uint32_t po_fold_selfs(uint32_t dim);   // self-paired words of a 4^k word space (0xFFFFFFFF: dim is not 4^k)
-int po_rc_fold(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, uint64_t n, uint32_t dim, uint32_t gran,
-               bool* folded, uint32_t* dim_f, uint32_t* dbl_at);
+#define PO_FOLD_ASYM 1u            // flag bits of the fold pass: some record is not reverse-complement symmetric
+#define PO_FOLD_NOT_ALL_TABLE 2u   // some 128-record block does not qualify for the JSD integer-sum table kernel
+#define PO_FOLD_NOT_ALL_SAD 4u     // some 128-record block does not qualify for the packed SAD kernel (BC)
+int po_rc_fold(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, const uint64_t* d_totals, uint64_t n,
+               uint32_t dim, uint32_t gran, bool* folded, uint32_t* dim_f, uint32_t* dbl_at, uint32_t* flags_out);
 // cls (may be NULL): per 128-record block, the common word total if the equal-total table path owns
 // the tiles of that class (po_jsd_lut.hip); valu_tile_kernel<JSD> skips tiles with equal non-zero classes.
 int po_launch_valu_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const unsigned long long* cls, uint64_t* tiles);
