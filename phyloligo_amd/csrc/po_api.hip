@@ -392,6 +392,9 @@ static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
         if (po_kt_mfma_supported(dim)) {      // uint8 ranks + word-pair items of the MFMA kernel
             rc = po_buf_reserve(ctx, &ctx->ws_freq, po_kt_mfma_workspace(n, dim));
             if (rc) return rc;
+        } else if (po_kt_panel_supported(dim)) {   // uint16 ranks of the panel kernel
+            rc = po_buf_reserve(ctx, &ctx->ws_freq, po_kt_panel_workspace(n, dim));
+            if (rc) return rc;
         }
     }
     if (metric == PO_JSD) {
@@ -509,20 +512,28 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     }
     if (rc) return rc;
     po_kt_mfma_plan kt_plan;
+    po_kt_panel_plan kt_pplan;
     memset(&kt_plan, 0, sizeof(kt_plan));
+    memset(&kt_pplan, 0, sizeof(kt_pplan));
     const bool kt_mfma = metric == PO_KT && po_kt_mfma_supported(dim) && !(flags & PO_FLAG_NO_TABLE_PATH);
-    if (kt_mfma) {
+    const bool kt_panel = metric == PO_KT && !kt_mfma && po_kt_panel_supported(dim) && !(flags & PO_FLAG_NO_TABLE_PATH);
+    if (kt_mfma || kt_panel) {
         // strand-symmetric records: Kendall's S over one word per reverse-complement orbit, weighted (po_fold.hip)
         const uint32_t selfs = po_fold_selfs(dim);
         const uint32_t* fold_src = nullptr;
-        if (!(flags & PO_FLAG_NO_RC_FOLD) && selfs != 0xFFFFFFFFu && po_kt_mfma_fold_supported(dim, selfs)) {
-            uint32_t dim_f = 0, at = 0;
-            rc = po_rc_fold(ctx, d_counts, d_freq, nullptr, n, dim, PO_FOLD_SELFS_FIRST, &folded, &dim_f, &at, nullptr);
+        uint32_t fold_len = 0;
+        const bool can_fold = selfs != 0xFFFFFFFFu &&
+                              (kt_mfma ? po_kt_mfma_fold_supported(dim, selfs) : po_kt_panel_fold_supported(dim, selfs));
+        if (!(flags & PO_FLAG_NO_RC_FOLD) && can_fold) {
+            uint32_t at = 0;
+            rc = po_rc_fold(ctx, d_counts, d_freq, nullptr, n, dim, PO_FOLD_SELFS_FIRST, &folded, &fold_len, &at, nullptr);
             if (rc) return rc;
             if (folded) fold_src = static_cast<const uint32_t*>(ctx->ws_fold_src.p);
         }
-        rc = po_launch_kt_mfma_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, fold_src, selfs, fold_src ? (dim - selfs) / 2 : 0,
-                                    &kt_plan);
+        const uint32_t n_pairs = fold_src ? (dim - selfs) / 2 : 0;
+        rc = kt_mfma ? po_launch_kt_mfma_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, fold_src, selfs, n_pairs, &kt_plan)
+                     : po_launch_kt_panel_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, fold_src, fold_len, selfs, n_pairs,
+                                               &kt_pplan);
         if (rc) return rc;
     }
     if (metric == PO_EUCL || (metric == PO_SC && !sc_i8)) {
@@ -597,6 +608,7 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
                 break;
             case PO_KT:
                 if (kt_mfma) { rc = po_launch_kt_mfma_tiles(ctx, a, ctx->ws_freq.p, kt_plan, &tiles); kid = PO_KERNEL_MFMA_I8_KT; }
+                else if (kt_panel) { rc = po_launch_kt_panel_tiles(ctx, a, ctx->ws_freq.p, kt_pplan, &tiles); kid = PO_KERNEL_MFMA_I8_KT; }
                 else { rc = po_launch_kt(ctx, lessrank, n, dim, a, &tiles); kid = PO_KERNEL_VALU_KT; }
                 break;
         }

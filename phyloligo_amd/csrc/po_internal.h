@@ -179,4 +179,17 @@ int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, 
                            const uint32_t* fold_src, uint32_t n_selfs, uint32_t n_pairs, po_kt_mfma_plan* plan);
 int po_launch_kt_mfma_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, const po_kt_mfma_plan& plan, uint64_t* tiles);
 
+// Kendall on the int8 matrix cores, 256 < dim <= 16384: 64-word rank panels (po_kt_panel.hip)
+bool po_kt_panel_supported(uint32_t dim);
+bool po_kt_panel_fold_supported(uint32_t dim, uint32_t n_selfs);
+size_t po_kt_panel_workspace(uint64_t n, uint32_t dim);
+struct po_kt_panel_plan {
+    uint32_t n_diag_items, words, row_words, self_panels;
+    int folded;
+};
+int po_launch_kt_panel_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, uint64_t npad, void* ws,
+                            const uint32_t* fold_src, uint32_t fold_src_len, uint32_t n_selfs, uint32_t n_pairs,
+                            po_kt_panel_plan* plan);
+int po_launch_kt_panel_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, const po_kt_panel_plan& plan, uint64_t* tiles);
+
 static inline uint64_t po_round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }

@@ -199,3 +199,26 @@ def test_kendall_single_strand_not_folded(ctx):
     got, st = ctx.pairwise(counts, totals, "KT", want_stats=True)
     assert not st["rc_folded"]
     assert np.array_equal(got, ctx.pairwise(counts, totals, "KT", table_path=False), equal_nan=True)
+
+
+@pytest.mark.parametrize("pattern,strand,expect_fold", [("11111", "both", True), ("11111", "plus", False),
+                                                        ("11011011", "both", True), ("110011", "minus", False),
+                                                        ("1111111", "both", True), ("101111", "both", False)])
+def test_kendall_panel_kernel_large_word_spaces(ctx, pattern, strand, expect_fold):
+    """k = 5..7 (D = 1 024 .. 16 384): the panelised int8-MFMA kernel (uint16 ranks, 64-word panels, folded or not)
+    against the O(D^2) VALU kernel - Kendall's S is an integer, so bit for bit."""
+    k = pattern.count("1")
+    n = 150 if k <= 6 else 70
+    contigs = contigs_ragged(n, 40 + k, lo=400, hi=2500)
+    seq, off = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, off, pattern, strand)
+    got, st = ctx.pairwise(counts, totals, "KT", want_stats=True)
+    assert st["kernel_id"] == 8 and st["rc_folded"] == expect_fold
+    valu, st0 = ctx.pairwise(counts, totals, "KT", want_stats=True, table_path=False)
+    assert st0["kernel_id"] == 5
+    assert np.array_equal(got, valu, equal_nan=True)
+    unfolded = ctx.pairwise(counts, totals, "KT", rc_fold=False)
+    assert np.array_equal(got, unfolded, equal_nan=True)
+    sub = ctx.pairwise(counts, totals, "KT", row_begin=5, row_end=133 if n > 133 else n - 3)
+    assert np.array_equal(sub, got[5:133 if n > 133 else n - 3], equal_nan=True)
+    assert np.array_equal(got, got.T, equal_nan=True) and np.all(np.diag(got)[totals > 0] == 1.0)
