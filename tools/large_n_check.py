@@ -22,10 +22,13 @@ print("N=%d %s: %.1f ms (kernel %.1f), %.3e pairs/s, kernel id %d, folded %s" % 
     n, metric, st["total_ms"], st["kernel_ms"], n * (n - 1) / 2 / (st["total_ms"] * 1e-3), st["kernel_id"], st["rc_folded"]), flush=True)
 freq = oracle.counts_to_frequencies(counts.cpu().numpy().astype(np.int64), totals.cpu().numpy())
 rows = [0, n // 3 + 17, n - 1]
+cols = np.arange(n) if metric != "KT" else np.sort(np.random.default_rng(1).choice(n, size=64, replace=False))   # the KT oracle is O(D^2) Python per pair
 for r in rows:
-    w = oracle.pairwise_block(np.vstack([freq[r:r + 1], freq]), metric, 0, 1)[0, 1:]
-    g = out[r].cpu().numpy()
-    w[r] = 0.0 if metric != "KT" else g[r]
+    w = oracle.pairwise_block(np.vstack([freq[r:r + 1], freq[cols]]), metric, 0, 1)[0, 1:]
+    g = out[r].cpu().numpy()[cols]
+    r = int(np.searchsorted(cols, r)) if r in cols else -1
+    if r >= 0:
+        w[r] = 0.0 if metric != "KT" else g[r]
     err = np.nanmax(np.abs(g - w) / np.maximum(np.abs(w), 1e-300) * (np.abs(w) > 1e-12))
     print("row %d: max rel err %.2e" % (r, err), flush=True)
     assert err < 1e-6
