@@ -66,7 +66,9 @@ def main():
     rehearsal = os.environ.get("PO_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    if world > 1:
+    # PO_BENCH_FORCE_DIST=1: take the torch.distributed path even with one rank (exercises the RCCL calls on a
+    # one-GPU box: process group, all_gather_into_tensor, barrier, all_reduce)
+    if world > 1 or os.environ.get("PO_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if rehearsal:
