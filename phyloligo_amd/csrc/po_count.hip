@@ -29,6 +29,8 @@ constexpr uint32_t kMaxLdsBins = 16384;            // 64 KiB histogram; above th
 
 struct CountParams {
     uint32_t window, k, dim, nruns, patbits;
+    uint32_t sym;          // -s both with a pattern that reads the same in both directions: count the forward words only and
+                           // write out hist[w] + hist[rc(w)] (seq + revcomp(seq) is its own reverse complement)
     uint32_t src_shift[PO_MAX_RUNS];
     uint32_t dst_shift[PO_MAX_RUNS];
     uint32_t mask[PO_MAX_RUNS];
@@ -196,7 +198,8 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     // ---- slide: lane owns starts [32 lane, 32 lane + 32) ---------------------------------------------
     const uint32_t W = P.window;
     const bool want_plus = P.strand != PO_STRAND_MINUS;
-    const bool want_minus = P.strand != PO_STRAND_PLUS;
+    const bool want_minus = P.strand != PO_STRAND_PLUS && !P.sym;
+    const uint32_t per_word = P.sym ? 2u : 1u;                      // a forward word also stands for its mirror window
     uint32_t mine_count = 0;
     {
         uint32_t cw[16];
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                             const uint32_t idx = word_index(fwd, P);
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
-                            ++mine_count;
+                            mine_count += per_word;
                         }
                         if (want_minus) {
                             const uint32_t idx = word_index(rev, P);
@@ -239,9 +242,15 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     }
 
     // ---- junction words of seq + revcomp(seq) (-s both), by the chunk holding the record end ----
+    // Symmetric mode: the W-1 junction windows are mirror images of each other (start p <-> 2L - W - p), so only the
+    // first of each pair is added (the write-out doubles it); for even W the middle window is its own mirror and
+    // spells a self-paired word, which is added once, after the doubling (mid_word).
+    uint32_t* mid_slot = reinterpret_cast<uint32_t*>(codes);        // the staged digits are no longer needed
+    if (P.sym && lane == 0) *mid_slot = 0xFFFFFFFFu;
     if (P.strand == PO_STRAND_BOTH && chunk == rec_chunks - 1 && lane < W - 1) {
         const int64_t p = L - (int64_t)W + 1 + (int64_t)lane;       // start in the 2L-long virtual string
-        if (p >= 0 && p < L && p + (int64_t)W <= 2 * L) {
+        const bool first_of_pair = 2 * p < 2 * L - (int64_t)W, middle = 2 * p == 2 * L - (int64_t)W;
+        if (p >= 0 && p < L && p + (int64_t)W <= 2 * L && (!P.sym || first_of_pair || middle)) {
             uint32_t idx = 0;
             bool ok = true;
             for (uint32_t x = 0; x < W; ++x) {
@@ -253,9 +262,14 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                 if ((P.patbits >> x) & 1u) idx = idx * 4u + (d & 3u);
             }
             if (ok) {
-                if (LDS_HIST) atomicAdd(&hist[idx], 1u);
-                else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
-                ++mine_count;
+                if (P.sym && middle) {
+                    *mid_slot = idx;
+                    ++mine_count;
+                } else {
+                    if (LDS_HIST) atomicAdd(&hist[idx], 1u);
+                    else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
+                    mine_count += per_word;
+                }
             }
         }
     }
@@ -271,12 +285,19 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     if (LDS_HIST) {
         __builtin_amdgcn_wave_barrier();
         uint32_t* row = counts + (uint64_t)rec * P.dim;
+        const uint32_t mid_word = P.sym ? *mid_slot : 0xFFFFFFFFu;
+        auto bin = [&](uint32_t d) -> uint32_t {
+            if (!P.sym) return hist[d];
+            uint32_t r = 0, w = d;                                  // reverse complement in the C,G,A,T digit coding
+            for (uint32_t i = 0; i < P.k; ++i) { r = (r << 2) | ((w & 3u) ^ 1u); w >>= 2; }
+            return hist[d] + hist[r] + (d == mid_word ? 1u : 0u);
+        };
         if (rec_chunks == 1) {
             for (uint32_t d = lane * 4; d < P.dim; d += 256)
-                *reinterpret_cast<uint4*>(row + d) = *reinterpret_cast<const uint4*>(hist + d);
+                *reinterpret_cast<uint4*>(row + d) = make_uint4(bin(d), bin(d + 1), bin(d + 2), bin(d + 3));
         } else {
             for (uint32_t d = lane; d < P.dim; d += 64) {
-                const uint32_t v = hist[d];
+                const uint32_t v = bin(d);
                 if (v) atomicAdd(&row[d], v);
             }
         }
@@ -320,6 +341,9 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     }
     for (uint32_t i = 0; i < pat.k; ++i) P.patbits |= 1u << pat.ones[i];
     P.strand = strand;
+    bool palindromic = true;
+    for (uint32_t x = 0; x < pat.window; ++x) palindromic = palindromic && (((P.patbits >> x) & 1u) == ((P.patbits >> (pat.window - 1 - x)) & 1u));
+    P.sym = (strand == PO_STRAND_BOTH && palindromic && pat.dim <= kMaxLdsBins) ? 1u : 0u;
     P.n_seqs = (uint32_t)n_seqs;
     P.total_bytes = total_bytes;
 
