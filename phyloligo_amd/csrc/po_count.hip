@@ -18,6 +18,8 @@
 // (phyloligo.py:141) are added by the chunk that holds the record's end.
 #include "po_internal.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -48,7 +50,8 @@ __device__ __forceinline__ uint32_t base_digit(uint32_t c) {
     return member ? d : 4u;
 }
 
-__device__ __forceinline__ uint32_t word_index(uint64_t reg, const CountParams& P) {
+template <typename REG>
+__device__ __forceinline__ uint32_t word_index(REG reg, const CountParams& P) {
     uint32_t idx = 0;
     for (uint32_t r = 0; r < P.nruns; ++r)
         idx |= ((uint32_t)(reg >> P.src_shift[r]) & P.mask[r]) << P.dst_shift[r];
@@ -130,7 +133,10 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
 }
 
 // ---- counting: one WAVE per chunk, no workgroup barrier -------------------------------------------
-template <bool LDS_HIST>
+// NARROW: 2 W <= 32, the rolling window registers are 32-bit (every contiguous k-mer up to k = 16).
+// MODE: which rolling registers the slide keeps - 0 forward only (plus strand, or both strands in symmetric mode),
+//       1 reverse only (minus strand), 2 both.
+template <bool LDS_HIST, bool NARROW, int MODE>
 __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restrict__ seq,
                                                          const uint64_t* __restrict__ begins,
                                                          const uint64_t* __restrict__ ends,
@@ -141,10 +147,11 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     extern __shared__ __align__(16) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave >= waves_per_block) return;
-    const uint32_t per_wave_words = kStage / 4 + (LDS_HIST ? P.dim : 0);
+    const uint32_t per_wave_words = kStage / 4 + 64 + (LDS_HIST ? P.dim : 0);
     uint32_t* mine = smem + wave * per_wave_words;
     uint8_t* codes = reinterpret_cast<uint8_t*>(mine);            // [kStage]
-    uint32_t* hist = mine + kStage / 4;                            // [dim] when LDS_HIST
+    uint8_t* dtab = reinterpret_cast<uint8_t*>(mine + kStage / 4); // [256] byte -> digit
+    uint32_t* hist = mine + kStage / 4 + 64;                       // [dim] when LDS_HIST
 
     const uint32_t b = blockIdx.x * waves_per_block + wave;
     const uint32_t nchunks = chunk_start[P.n_seqs];
@@ -167,7 +174,16 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     if (LDS_HIST)
         for (uint32_t d = lane * 4; d < P.dim; d += 256) *reinterpret_cast<uint4*>(hist + d) = make_uint4(0, 0, 0, 0);
 
-    // ---- stage + decode (aligned 16-byte loads, one decode per base) ---------------------------
+    // ---- stage + decode (aligned 16-byte loads, one table lookup per base) -------------------------
+    // the byte -> digit map as a 256-byte LDS table of the wave (each lane evaluates four entries): a lookup costs
+    // one LDS read instead of ~8 vector-ALU instructions, and this kernel is ALU-bound
+    {
+        uint32_t e = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e |= base_digit(lane * 4 + i) << (8 * i);
+        reinterpret_cast<uint32_t*>(dtab)[lane] = e;
+    }
+    __builtin_amdgcn_wave_barrier();
     for (uint32_t v = lane; v < kStage / 16; v += 64) {
         const uint64_t a = a0 + (uint64_t)v * 16;
         uint32_t w[4] = {0, 0, 0, 0};
@@ -178,18 +194,19 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
             for (int i = 0; i < 16; ++i)
                 if (a + i < P.total_bytes) w[i >> 2] |= (uint32_t)seq[a + i] << (8 * (i & 3));
         }
-        const int64_t pos = pos0 + (int64_t)v * 16;
+        const int64_t left = L - (pos0 + (int64_t)v * 16);          // bytes of this vector that belong to the record
+        const int32_t nvalid = (int32_t)max((int64_t)0, min(left, (int64_t)16));
         uint32_t o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint32_t packed = 0;
+        for (int j = 0; j < 4; ++j)
+            o[j] = (uint32_t)dtab[w[j] & 0xFFu] | ((uint32_t)dtab[(w[j] >> 8) & 0xFFu] << 8) |
+                   ((uint32_t)dtab[(w[j] >> 16) & 0xFFu] << 16) | ((uint32_t)dtab[w[j] >> 24] << 24);
+        if (nvalid < 16) {                                          // the vector holding the record end (and beyond): separators
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t d = base_digit((w[j] >> (8 * i)) & 0xFFu);
-                if (pos + j * 4 + i >= L) d = 4u;                   // bytes of the next record
-                packed |= d << (8 * i);
-            }
-            o[j] = packed;
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (j * 4 + i >= nvalid) o[j] = (o[j] & ~(0xFFu << (8 * i))) | (4u << (8 * i));
         }
         *reinterpret_cast<uint4*>(codes + v * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -197,19 +214,22 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
 
     // ---- slide: lane owns starts [32 lane, 32 lane + 32) ---------------------------------------------
     const uint32_t W = P.window;
-    const bool want_plus = P.strand != PO_STRAND_MINUS;
-    const bool want_minus = P.strand != PO_STRAND_PLUS && !P.sym;
+    constexpr bool want_plus = MODE != 1, want_minus = MODE != 0;
     const uint32_t per_word = P.sym ? 2u : 1u;                      // a forward word also stands for its mirror window
     uint32_t mine_count = 0;
     {
+        typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type reg_t;
         uint32_t cw[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint4 v = *reinterpret_cast<const uint4*>(codes + lane * kPerLane + 16 * q);
             cw[4 * q] = v.x; cw[4 * q + 1] = v.y; cw[4 * q + 2] = v.z; cw[4 * q + 3] = v.w;
         }
-        const int64_t first = pos0 + (int64_t)lane * kPerLane;     // record position of this lane's start 0
-        uint64_t fwd = 0, rev = 0;
+        // this lane's window starts s = 0..31 sit at record positions first + s; those in [p_lo, p_hi) are ours
+        const int64_t first = pos0 + (int64_t)lane * kPerLane;
+        const int64_t lo64 = p_lo - first, hi64 = p_hi - first;
+        const int32_t s_lo = (int32_t)max(lo64, (int64_t)0), s_hi = (int32_t)min(hi64, (int64_t)kPerLane);
+        reg_t fwd = 0, rev = 0;
         uint32_t run = 0;
         const uint32_t top = 2 * W - 2;
 #pragma unroll
@@ -217,20 +237,19 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
             if (i < (int)(kPerLane + W - 1)) {                      // uniform
                 const uint32_t d = (cw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
                 run = (d < 4u) ? run + 1u : 0u;
-                fwd = (fwd << 2) | (uint64_t)(d & 3u);
-                rev = (rev >> 2) | ((uint64_t)((d & 3u) ^ 1u) << top);
-                const int s = i - (int)(W - 1);                     // window start index of this lane
+                if (want_plus) fwd = (fwd << 2) | (reg_t)(d & 3u);
+                if (want_minus) rev = (rev >> 2) | ((reg_t)((d & 3u) ^ 1u) << top);
+                const int s = i - (int)(W - 1);                     // window start index of this lane (uniform)
                 if (s >= 0) {
-                    const int64_t p = first + s;
-                    if (run >= W && p >= p_lo && p < p_hi) {
+                    if (run >= W && s >= s_lo && s < s_hi) {
                         if (want_plus) {
-                            const uint32_t idx = word_index(fwd, P);
+                            const uint32_t idx = word_index<reg_t>(fwd, P);
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                             mine_count += per_word;
                         }
                         if (want_minus) {
-                            const uint32_t idx = word_index(rev, P);
+                            const uint32_t idx = word_index<reg_t>(rev, P);
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                             ++mine_count;
@@ -348,19 +367,27 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     P.total_bytes = total_bytes;
 
     const bool lds_hist = pat.dim <= kMaxLdsBins;
-    const size_t per_wave = kStage + (lds_hist ? (size_t)pat.dim * 4 : 0);
+    const size_t per_wave = kStage + 256 + (lds_hist ? (size_t)pat.dim * 4 : 0);
     uint32_t wpb = (uint32_t)((80u << 10) / per_wave);                // waves per workgroup within 80 KiB of LDS
     wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
     const size_t shmem = per_wave * wpb;
     const uint32_t grid = (uint32_t)((max_chunks + wpb - 1) / wpb);
     unsigned long long* tot = reinterpret_cast<unsigned long long*>(d_totals);
-    if (lds_hist) {
-        auto k = count_kernel<true>;
+    const bool narrow = 2 * pat.window <= 32;
+    const int mode = (strand == PO_STRAND_PLUS || P.sym) ? 0 : (strand == PO_STRAND_MINUS ? 1 : 2);
+    auto launch = [&](auto k) -> int {
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), shmem, ctx->stream, d_seq, d_begins, d_ends, chunk_start, P, wpb, d_counts, tot);
-    } else {
-        hipLaunchKernelGGL(count_kernel<false>, dim3(grid), dim3(kThreads), shmem, ctx->stream, d_seq, d_begins, d_ends, chunk_start, P, wpb, d_counts, tot);
-    }
+        return PO_OK;
+    };
+    int lrc = PO_OK;
+#define PO_COUNT_CASE(L, N, M) if (lds_hist == L && narrow == N && mode == M) lrc = launch(count_kernel<L, N, M>);
+    PO_COUNT_CASE(true, true, 0) PO_COUNT_CASE(true, true, 1) PO_COUNT_CASE(true, true, 2)
+    PO_COUNT_CASE(true, false, 0) PO_COUNT_CASE(true, false, 1) PO_COUNT_CASE(true, false, 2)
+    PO_COUNT_CASE(false, true, 0) PO_COUNT_CASE(false, true, 1) PO_COUNT_CASE(false, true, 2)
+    PO_COUNT_CASE(false, false, 0) PO_COUNT_CASE(false, false, 1) PO_COUNT_CASE(false, false, 2)
+#undef PO_COUNT_CASE
+    if (lrc) return lrc;
     PO_CHECK_LAUNCH("count_kernel");
     return PO_OK;
 }
