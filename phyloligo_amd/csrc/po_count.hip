@@ -50,8 +50,11 @@ __device__ __forceinline__ uint32_t base_digit(uint32_t c) {
     return member ? d : 4u;
 }
 
-template <typename REG>
+// SIMPLE: a contiguous k-mer (one run, no gaps): the word is the low 2k bits of the forward register /
+// the top 2k bits of the 2W-bit reverse register, which for W = k is the whole register
+template <typename REG, bool SIMPLE>
 __device__ __forceinline__ uint32_t word_index(REG reg, const CountParams& P) {
+    if (SIMPLE) return (uint32_t)reg & (P.dim - 1u);
     uint32_t idx = 0;
     for (uint32_t r = 0; r < P.nruns; ++r)
         idx |= ((uint32_t)(reg >> P.src_shift[r]) & P.mask[r]) << P.dst_shift[r];
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
 // NARROW: 2 W <= 32, the rolling window registers are 32-bit (every contiguous k-mer up to k = 16).
 // MODE: which rolling registers the slide keeps - 0 forward only (plus strand, or both strands in symmetric mode),
 //       1 reverse only (minus strand), 2 both.
-template <bool LDS_HIST, bool NARROW, int MODE>
+template <bool LDS_HIST, bool NARROW, int MODE, bool SIMPLE>
 __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restrict__ seq,
                                                          const uint64_t* __restrict__ begins,
                                                          const uint64_t* __restrict__ ends,
@@ -156,10 +159,16 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     const uint32_t b = blockIdx.x * waves_per_block + wave;
     const uint32_t nchunks = chunk_start[P.n_seqs];
     if (b >= nchunks) return;                                      // grid is an upper bound
-    uint32_t lo = 0, hi = P.n_seqs;                                // last record with chunk_start <= b
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (chunk_start[mid] <= b) lo = mid; else hi = mid;
+    // record of chunk b = last record with chunk_start <= b.  When every record so far is a single chunk (any
+    // assembly of contigs up to 2 kb) that is record b itself: two loads instead of a 16-step dependent search.
+    uint32_t lo = 0, hi = P.n_seqs;
+    if (b < P.n_seqs && chunk_start[b] <= b && b < chunk_start[b + 1]) {
+        lo = b;
+    } else {
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (chunk_start[mid] <= b) lo = mid; else hi = mid;
+        }
     }
     const uint32_t rec = lo;
     const uint32_t chunk = b - chunk_start[rec];
@@ -184,16 +193,30 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
         reinterpret_cast<uint32_t*>(dtab)[lane] = e;
     }
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t v = lane; v < kStage / 16; v += 64) {
+    // all of the lane's 16-byte loads first (up to three HBM round trips in flight at once), then the decoding
+    constexpr int kVecPerLane = (kStage / 16 + 63) / 64;
+    uint4 raw[kVecPerLane];
+#pragma unroll
+    for (int it = 0; it < kVecPerLane; ++it) {
+        const uint32_t v = lane + 64 * it;
         const uint64_t a = a0 + (uint64_t)v * 16;
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (a + 16 <= P.total_bytes) {
-            const uint4 q = *reinterpret_cast<const uint4*>(seq + a);
-            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-        } else {
-            for (int i = 0; i < 16; ++i)
-                if (a + i < P.total_bytes) w[i >> 2] |= (uint32_t)seq[a + i] << (8 * (i & 3));
+        raw[it] = make_uint4(0, 0, 0, 0);
+        if (v < kStage / 16) {
+            if (a + 16 <= P.total_bytes) {
+                raw[it] = *reinterpret_cast<const uint4*>(seq + a);
+            } else {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (int i = 0; i < 16; ++i)
+                    if (a + i < P.total_bytes) w[i >> 2] |= (uint32_t)seq[a + i] << (8 * (i & 3));
+                raw[it] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
         }
+    }
+#pragma unroll
+    for (int it = 0; it < kVecPerLane; ++it) {
+        const uint32_t v = lane + 64 * it;
+        if (v >= kStage / 16) break;
+        const uint32_t w[4] = {raw[it].x, raw[it].y, raw[it].z, raw[it].w};
         const int64_t left = L - (pos0 + (int64_t)v * 16);          // bytes of this vector that belong to the record
         const int32_t nvalid = (int32_t)max((int64_t)0, min(left, (int64_t)16));
         uint32_t o[4];
@@ -243,13 +266,13 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                 if (s >= 0) {
                     if (run >= W && s >= s_lo && s < s_hi) {
                         if (want_plus) {
-                            const uint32_t idx = word_index<reg_t>(fwd, P);
+                            const uint32_t idx = word_index<reg_t, SIMPLE>(fwd, P);
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                             mine_count += per_word;
                         }
                         if (want_minus) {
-                            const uint32_t idx = word_index<reg_t>(rev, P);
+                            const uint32_t idx = word_index<reg_t, SIMPLE>(rev, P);
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                             ++mine_count;
@@ -264,7 +287,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     // Symmetric mode: the W-1 junction windows are mirror images of each other (start p <-> 2L - W - p), so only the
     // first of each pair is added (the write-out doubles it); for even W the middle window is its own mirror and
     // spells a self-paired word, which is added once, after the doubling (mid_word).
-    uint32_t* mid_slot = reinterpret_cast<uint32_t*>(codes);        // the staged digits are no longer needed
+    uint32_t* mid_slot = reinterpret_cast<uint32_t*>(dtab);         // the decode table is no longer needed
     if (P.sym && lane == 0) *mid_slot = 0xFFFFFFFFu;
     if (P.strand == PO_STRAND_BOTH && chunk == rec_chunks - 1 && lane < W - 1) {
         const int64_t p = L - (int64_t)W + 1 + (int64_t)lane;       // start in the 2L-long virtual string
@@ -275,7 +298,9 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
             for (uint32_t x = 0; x < W; ++x) {
                 const int64_t q = p + x;
                 const bool fw = q < L;
-                uint32_t d = base_digit(seq[off + (uint64_t)(fw ? q : 2 * L - 1 - q)]);
+                const int64_t qpos = fw ? q : 2 * L - 1 - q;        // record position of the base (the last W-1 of the record)
+                uint32_t d = (qpos >= pos0) ? (uint32_t)codes[qpos - pos0]               // staged digits of this chunk
+                                            : base_digit(seq[off + (uint64_t)qpos]);     // short last chunk: before the staged range
                 ok = ok && (d < 4u);
                 if (!fw) d ^= 1u;
                 if ((P.patbits >> x) & 1u) idx = idx * 4u + (d & 3u);
@@ -381,7 +406,10 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
         return PO_OK;
     };
     int lrc = PO_OK;
-#define PO_COUNT_CASE(L, N, M) if (lds_hist == L && narrow == N && mode == M) lrc = launch(count_kernel<L, N, M>);
+    // contiguous k-mer: one run that takes the low 2k bits as they are (the reverse register then holds exactly 2W = 2k bits)
+    const bool simple = pat.nruns == 1 && pat.src_shift[0] == 0 && pat.dst_shift[0] == 0 && pat.window == pat.k;
+#define PO_COUNT_CASE(L, N, M) \
+    if (lds_hist == L && narrow == N && mode == M) lrc = simple ? launch(count_kernel<L, N, M, true>) : launch(count_kernel<L, N, M, false>);
     PO_COUNT_CASE(true, true, 0) PO_COUNT_CASE(true, true, 1) PO_COUNT_CASE(true, true, 2)
     PO_COUNT_CASE(true, false, 0) PO_COUNT_CASE(true, false, 1) PO_COUNT_CASE(true, false, 2)
     PO_COUNT_CASE(false, true, 0) PO_COUNT_CASE(false, true, 1) PO_COUNT_CASE(false, true, 2)
