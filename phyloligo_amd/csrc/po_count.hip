@@ -50,12 +50,18 @@ __device__ __forceinline__ uint32_t base_digit(uint32_t c) {
     return member ? d : 4u;
 }
 
-// SIMPLE: a contiguous k-mer (one run, no gaps): the word is the low 2k bits of the forward register /
-// the top 2k bits of the 2W-bit reverse register, which for W = k is the whole register
-template <typename REG, bool SIMPLE>
+// RUNS: -1 = a contiguous k-mer (one run, no gaps): the word is the low 2k bits of the forward register / the
+// whole 2W = 2k bit reverse register; 1..4 = that many (shift, mask, shift) runs, unrolled with the run parameters
+// in scalar registers; 0 = any number of runs (loop).
+template <typename REG, int RUNS>
 __device__ __forceinline__ uint32_t word_index(REG reg, const CountParams& P) {
-    if (SIMPLE) return (uint32_t)reg & (P.dim - 1u);
+    if (RUNS < 0) return (uint32_t)reg & (P.dim - 1u);
     uint32_t idx = 0;
+    if (RUNS > 0) {
+#pragma unroll
+        for (int r = 0; r < RUNS; ++r) idx |= ((uint32_t)(reg >> P.src_shift[r]) & P.mask[r]) << P.dst_shift[r];
+        return idx;
+    }
     for (uint32_t r = 0; r < P.nruns; ++r)
         idx |= ((uint32_t)(reg >> P.src_shift[r]) & P.mask[r]) << P.dst_shift[r];
     return idx;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
 // NARROW: 2 W <= 32, the rolling window registers are 32-bit (every contiguous k-mer up to k = 16).
 // MODE: which rolling registers the slide keeps - 0 forward only (plus strand, or both strands in symmetric mode),
 //       1 reverse only (minus strand), 2 both.
-template <bool LDS_HIST, bool NARROW, int MODE, bool SIMPLE>
+template <bool LDS_HIST, bool NARROW, int MODE, int RUNS>
 __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restrict__ seq,
                                                          const uint64_t* __restrict__ begins,
                                                          const uint64_t* __restrict__ ends,
@@ -266,13 +272,13 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                 if (s >= 0) {
                     if (run >= W && s >= s_lo && s < s_hi) {
                         if (want_plus) {
-                            const uint32_t idx = word_index<reg_t, SIMPLE>(fwd, P);
+                            const uint32_t idx = word_index<reg_t, RUNS>(fwd, P);
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                             mine_count += per_word;
                         }
                         if (want_minus) {
-                            const uint32_t idx = word_index<reg_t, SIMPLE>(rev, P);
+                            const uint32_t idx = word_index<reg_t, RUNS>(rev, P);
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                             ++mine_count;
@@ -408,12 +414,18 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     int lrc = PO_OK;
     // contiguous k-mer: one run that takes the low 2k bits as they are (the reverse register then holds exactly 2W = 2k bits)
     const bool simple = pat.nruns == 1 && pat.src_shift[0] == 0 && pat.dst_shift[0] == 0 && pat.window == pat.k;
-#define PO_COUNT_CASE(L, N, M) \
-    if (lds_hist == L && narrow == N && mode == M) lrc = simple ? launch(count_kernel<L, N, M, true>) : launch(count_kernel<L, N, M, false>);
+    const int runs = simple ? -1 : (pat.nruns <= 4 ? (int)pat.nruns : 0);
+#define PO_COUNT_RUNS(L, N, M, R) if (runs == R) lrc = launch(count_kernel<L, N, M, R>);
+#define PO_COUNT_CASE(L, N, M)                                                                                  \
+    if (lds_hist == L && narrow == N && mode == M) {                                                            \
+        PO_COUNT_RUNS(L, N, M, -1) PO_COUNT_RUNS(L, N, M, 0) PO_COUNT_RUNS(L, N, M, 1) PO_COUNT_RUNS(L, N, M, 2) \
+        PO_COUNT_RUNS(L, N, M, 3) PO_COUNT_RUNS(L, N, M, 4)                                                      \
+    }
     PO_COUNT_CASE(true, true, 0) PO_COUNT_CASE(true, true, 1) PO_COUNT_CASE(true, true, 2)
     PO_COUNT_CASE(true, false, 0) PO_COUNT_CASE(true, false, 1) PO_COUNT_CASE(true, false, 2)
     PO_COUNT_CASE(false, true, 0) PO_COUNT_CASE(false, true, 1) PO_COUNT_CASE(false, true, 2)
     PO_COUNT_CASE(false, false, 0) PO_COUNT_CASE(false, false, 1) PO_COUNT_CASE(false, false, 2)
+#undef PO_COUNT_RUNS
 #undef PO_COUNT_CASE
     if (lrc) return lrc;
     PO_CHECK_LAUNCH("count_kernel");
