@@ -68,9 +68,10 @@ __global__ __launch_bounds__(128) void classify_kernel(const unsigned long long*
     if (threadIdx.x == 0) cls[blockIdx.x] = (all && ref > 0 && 2u * *maxcount < (uint32_t)kLutEntries) ? ref : 0ull;
 }
 
+// the table as the tile kernels want it in LDS: entry x replicated 32 times (copy c at x*32 + c)
 __global__ void lut_table_kernel(double* __restrict__ lut) {
-    const uint32_t x = threadIdx.x;
-    if (x < kLutEntries) lut[x] = x ? (double)x * log((double)x) : 0.0;
+    const uint32_t x = blockIdx.x;
+    lut[x * 32 + threadIdx.x] = x ? (double)x * log((double)x) : 0.0;
 }
 
 
@@ -96,7 +97,11 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void jsd_lut_tile_ker
     if (ntot == 0 || cls[tj] != ntot) return;                                    // valu_tile_kernel<JSD> owns this tile
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
 
-    for (uint32_t e = t; e < kLutEntries * 32; e += NT) tab[e] = lut[e >> 5];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(lut);                  // already replicated: 16-byte copies
+        uint4* dst = reinterpret_cast<uint4*>(tab);
+        for (uint32_t v = t; v < kLutBytes / 16; v += NT) dst[v] = src[v];
+    }
 
     double acc[RPT][8];
 #pragma unroll
@@ -198,8 +203,8 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void jsd_lut_tile_ker
 size_t po_jsd_lut_workspace(uint64_t n, uint32_t dim) {
     const uint64_t npad = po_round_up(n ? n : 1, 128);
     return po_round_up(dim, 8) * npad * sizeof(uint32_t)      // Ct
-           + npad / 128 * sizeof(unsigned long long)            // cls
-           + kLutEntries * sizeof(double) + 256;                // T + maxcount
+           + po_round_up(npad / 128 * sizeof(unsigned long long), 16)   // cls
+           + kLutBytes + 256;                                   // replicated T + maxcount
 }
 
 // Builds Ct, the table and the tile classes in ws (layout as sized above); returns the class array.
@@ -209,14 +214,14 @@ int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t
     uint32_t* ct = reinterpret_cast<uint32_t*>(base);
     base += po_round_up(dim, 8) * npad * sizeof(uint32_t);
     unsigned long long* cls = reinterpret_cast<unsigned long long*>(base);
-    base += npad / 128 * sizeof(unsigned long long);
+    base += po_round_up(npad / 128 * sizeof(unsigned long long), 16);
     double* lut = reinterpret_cast<double*>(base);
-    uint32_t* maxcount = reinterpret_cast<uint32_t*>(base + kLutEntries * sizeof(double));
+    uint32_t* maxcount = reinterpret_cast<uint32_t*>(base + kLutBytes);
     PO_HIP(hipMemsetAsync(maxcount, 0, sizeof(uint32_t), ctx->stream));
     dim3 grid((uint32_t)(npad / 64), (dim + 63) / 64);
     hipLaunchKernelGGL(prep_counts_kernel, grid, dim3(256), 0, ctx->stream, d_counts, n, dim, npad, ct, maxcount);
     PO_CHECK_LAUNCH("prep_counts_kernel");
-    hipLaunchKernelGGL(lut_table_kernel, dim3(1), dim3(kLutEntries), 0, ctx->stream, lut);
+    hipLaunchKernelGGL(lut_table_kernel, dim3(kLutEntries), dim3(32), 0, ctx->stream, lut);
     PO_CHECK_LAUNCH("lut_table_kernel");
     hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, ctx->stream,
                        reinterpret_cast<const unsigned long long*>(d_totals), n, maxcount, d_wsum, cls);
@@ -230,7 +235,7 @@ int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, cons
     const uint32_t* ct = reinterpret_cast<const uint32_t*>(base);
     base += po_round_up(a.dim, 8) * a.npad * sizeof(uint32_t);
     const unsigned long long* cls = reinterpret_cast<const unsigned long long*>(base);
-    base += a.npad / 128 * sizeof(unsigned long long);
+    base += po_round_up(a.npad / 128 * sizeof(unsigned long long), 16);
     const double* lut = reinterpret_cast<const double*>(base);
     (void)n;
     const uint64_t nblocks = po_tile_count(a, TM);
