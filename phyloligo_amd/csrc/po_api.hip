@@ -492,12 +492,19 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     const uint32_t i8_upto = po_gram_i8_value_limit(dim);
     // Spearman: the doubled centred ranks are small integers -> the same exact int8 kernel (two digit planes)
     const bool sc_i8 = metric == PO_SC && po_gram_i8_sc_supported(dim) && !(flags & PO_FLAG_NO_TABLE_PATH);
-    if (metric == PO_EUCL || metric == PO_JSD || metric == PO_BC) {
+    // the fold pass may have established that the equal-total kernels own every tile: the float64 operand matrix
+    // is then not needed at all and the per-record terms come straight from the counts
+    const bool all_table = d_counts && !(flags & PO_FLAG_NO_TABLE_PATH) &&
+                           ((metric == PO_JSD && !(fold_flags & PO_FOLD_NOT_ALL_TABLE)) ||
+                            (metric == PO_BC && !(fold_flags & PO_FOLD_NOT_ALL_SAD)));
+    if ((metric == PO_EUCL || metric == PO_JSD || metric == PO_BC) && !all_table) {
         rc = d_freq ? po_launch_prep_freq(ctx, d_freq, n, dim, npad, ft)
                     : po_launch_prep(ctx, d_counts, d_totals, n, dim, npad, ft, i8flag, i8_upto);
         if (rc) return rc;
     }
-    if (metric == PO_JSD || metric == PO_BC) {
+    if (all_table) {
+        rc = po_launch_rowstat_counts(ctx, d_counts, d_totals, n, dim, npad, rowstat, metric == PO_JSD, dbl_at);
+    } else if (metric == PO_JSD || metric == PO_BC) {
         rc = po_launch_rowstat(ctx, ft, n, dim, npad, rowstat, metric == PO_JSD ? ctx->ws_logtab.p : nullptr, dbl_at);
     } else if (sc_i8) {
         int32_t* r2 = static_cast<int32_t*>(ctx->ws_freq.p);           // the float64 operand buffer is free on this path

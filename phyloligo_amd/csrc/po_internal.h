@@ -105,6 +105,11 @@ int po_launch_freq_rowmajor(po_ctx* ctx, const uint32_t* d_counts, const uint64_
 int po_launch_rowstat(po_ctx* ctx, const double* d_ft, uint64_t n, uint32_t dim, uint64_t npad, double* d_rowstat,
                       const void* logtab, uint32_t dbl_at);
 
+// rowstat[0] (sum f ln f, when asked) and rowstat[1] (sum f) straight from integer counts: used instead of the float64
+// operand matrix + po_launch_rowstat when the equal-total kernels are known to own every tile
+int po_launch_rowstat_counts(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                             uint64_t npad, double* d_rowstat, bool want_entropy, uint32_t dbl_at);
+
 // One rectangular block of the matrix handed to a tile kernel.
 struct po_tile_args {
     const double* ft;       // operand matrix [dim8][npad] (frequencies or centred ranks)

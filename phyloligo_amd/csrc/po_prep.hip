@@ -99,7 +99,48 @@ __global__ __launch_bounds__(256) void rowstat_kernel(const double* __restrict__
     if (logtab != nullptr) rowstat[2 * npad + r] = et;
 }
 
+// The same per-record terms straight from integer counts, for calls in which the equal-total kernels own every tile
+// (the float64 operand matrix is then never read, so it is not built):
+//   rowstat[1][r] = sum_w c / n            rowstat[0][r] = sum_w (c/n) ln (c/n) = (sum_w c ln c) / n - (sum_w c / n) ln n
+// One wave per record; folded records (po_fold.hip) count the words before dbl_at twice.
+__global__ __launch_bounds__(256) void rowstat_counts_kernel(const uint32_t* __restrict__ counts,
+                                                             const unsigned long long* __restrict__ totals, uint64_t n,
+                                                             uint32_t dim, uint64_t npad, uint32_t dbl_at, int want_entropy,
+                                                             double* __restrict__ rowstat) {
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (r >= npad) return;
+    unsigned long long sum = 0;
+    double tsum = 0.0;
+    if (r < n) {
+        for (uint32_t d = lane; d < dim; d += 64) {
+            const uint32_t c = counts[r * dim + d];
+            const uint32_t wgt = (dbl_at != PO_NO_DOUBLING && d < dbl_at) ? 2u : 1u;
+            sum += (unsigned long long)c * wgt;
+            if (want_entropy && c > 1u) tsum += (double)wgt * ((double)c * log((double)c));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_down(sum, o, 64);
+        tsum += __shfl_down(tsum, o, 64);
+    }
+    if (lane == 0) {
+        const unsigned long long tot = (r < n) ? totals[r] : 0ull;
+        const double w = tot ? (double)sum / (double)tot : 0.0;
+        rowstat[npad + r] = w;
+        if (want_entropy) rowstat[r] = tot ? tsum / (double)tot - w * log((double)tot) : 0.0;
+    }
+}
+
 }  // namespace
+
+int po_launch_rowstat_counts(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
+                             uint64_t npad, double* d_rowstat, bool want_entropy, uint32_t dbl_at) {
+    hipLaunchKernelGGL(rowstat_counts_kernel, dim3((uint32_t)((npad + 3) / 4)), dim3(256), 0, ctx->stream, d_counts,
+                       reinterpret_cast<const unsigned long long*>(d_totals), n, dim, npad, dbl_at, want_entropy ? 1 : 0, d_rowstat);
+    PO_CHECK_LAUNCH("rowstat_counts_kernel");
+    return PO_OK;
+}
 
 int po_launch_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
                    uint64_t npad, double* d_ft, const uint32_t* skip_flag, uint32_t skip_upto) {
