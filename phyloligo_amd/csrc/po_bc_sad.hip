@@ -106,21 +106,26 @@ __global__ __launch_bounds__(kThreads, 2) void bc_sad_tile_kernel(po_tile_args A
         if (g0 == dbl_group) double_sums();
         const uint32_t* sA = stage + cur * kStageWords + ty * 8;
         const uint32_t* sB = stage + cur * kStageWords + KC * TM + tx * 2;
-#pragma unroll 4
-        for (int k = 0; k < KC; ++k) {
+        // fragments of group k+1 are read from LDS while the 64 SADs of group k issue
+        auto frag = [&](int k, uint32_t (&a)[8], uint32_t (&b)[8]) {
             const uint4 a0 = *reinterpret_cast<const uint4*>(sA + k * TM);
             const uint4 a1 = *reinterpret_cast<const uint4*>(sA + k * TM + 4);
-            const uint32_t a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            uint32_t b[8];
+            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint2 bv = *reinterpret_cast<const uint2*>(sB + k * TN + 32 * q);
                 b[2 * q] = bv.x; b[2 * q + 1] = bv.y;
             }
+        };
+        uint32_t fa[2][8], fb[2][8];
+        frag(0, fa[0], fb[0]);
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            if (k + 1 < KC) frag(k + 1, fa[(k + 1) & 1], fb[(k + 1) & 1]);
 #pragma unroll
             for (int ia = 0; ia < 8; ++ia)
 #pragma unroll
-                for (int ib = 0; ib < 8; ++ib) acc[ia][ib] = __builtin_amdgcn_sad_u8(a[ia], b[ib], acc[ia][ib]);
+                for (int ib = 0; ib < 8; ++ib) acc[ia][ib] = __builtin_amdgcn_sad_u8(fa[k & 1][ia], fb[k & 1][ib], acc[ia][ib]);
         }
         __syncthreads();
         cur ^= 1;
