@@ -68,7 +68,10 @@ typedef enum po_dtype { PO_F64 = 0, PO_F32 = 1 } po_dtype;
 
 #define PO_FLAG_NO_TABLE_PATH 2u /* general kernels only: no integer-sum table kernel for JSD record blocks with
                                    equal word totals, no exact int8-MFMA kernel for Eucl / SC,
-                                   no packed-byte SAD kernel for BC, no int8-MFMA kernel for KT           */
+                                   no packed-byte SAD kernel for BC, no int8-MFMA kernel for KT, and frequency
+                                   input is not traced back to integer profiles (po_pairwise_freq*: by default
+                                   a matrix whose every entry is count / total bit for bit, i.e. count2freq output,
+                                   is; that check reads one flag word back)                              */
 
 #define PO_FLAG_NO_RC_FOLD 4u /* JSD / BC / KT: do not look for reverse-complement symmetric profiles.  By default
                                  the input is checked on the device (count[w] == count[rc(w)] for every record

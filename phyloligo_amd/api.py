@@ -164,10 +164,12 @@ class Context:
                               (0 if table_path else PO_FLAG_NO_TABLE_PATH) | (0 if rc_fold else PO_FLAG_NO_RC_FOLD))
 
     def pairwise_freq(self, freq, metric="Eucl", row_begin=0, row_end=None, dtype="float64", symmetric=True,
-                      out=None, want_stats=False, rc_fold=True):
-        """The same from a float64 frequency matrix (the reference's `frequencies` argument)."""
+                      out=None, want_stats=False, rc_fold=True, table_path=True):
+        """The same from a float64 frequency matrix (the reference's `frequencies` argument).  Frequencies that are
+        count / total bit for bit (count2freq output) are traced back to the integer profiles on the device and take
+        the same kernels as `pairwise`; table_path=False keeps the general float64 kernels."""
         return self._pairwise(None, None, freq, metric, row_begin, row_end, dtype, symmetric, out, want_stats,
-                              0 if rc_fold else PO_FLAG_NO_RC_FOLD)
+                              (0 if rc_fold else PO_FLAG_NO_RC_FOLD) | (0 if table_path else PO_FLAG_NO_TABLE_PATH))
 
     def pairwise_blocks(self, counts, totals, metric, blocks, dtype="float64", want_stats=False, table_path=True,
                         rc_fold=True):

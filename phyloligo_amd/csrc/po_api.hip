@@ -89,6 +89,7 @@ extern "C" void po_ctx_destroy(po_ctx* ctx) {
     buf_free(&ctx->ws_logtab);
     buf_free(&ctx->ws_fold);
     buf_free(&ctx->ws_fold_src);
+    buf_free(&ctx->ws_recover);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     for (int i = 0; i < 2; ++i)
         if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
@@ -463,6 +464,19 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     double* rowstat = static_cast<double*>(ctx->ws_rowstat.p);
 
     if (stats) PO_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    // ---- frequencies that are count2freq output: back to the exact integer profiles (po_recover.hip) ----
+    if (d_freq && !(flags & PO_FLAG_NO_TABLE_PATH)) {
+        bool recovered = false;
+        const uint32_t* rc_counts = nullptr;
+        const uint64_t* rc_totals = nullptr;
+        rc = po_recover_counts(ctx, d_freq, n, dim, &recovered, &rc_counts, &rc_totals);
+        if (rc) return rc;
+        if (recovered) {
+            d_counts = rc_counts;
+            d_totals = rc_totals;
+            d_freq = nullptr;
+        }
+    }
     // ---- strand-symmetric profiles: one word per reverse-complement orbit (JSD, BC; po_fold.hip) ----
     uint32_t dbl_at = PO_NO_DOUBLING;
     bool folded = false;

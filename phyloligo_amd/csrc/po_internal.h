@@ -57,6 +57,7 @@ struct po_ctx {
     bool logtab_ready = false;
     po_buf ws_fold;                    // reverse-complement folded counts / frequencies (po_fold.hip) + flag word
     po_buf ws_fold_src;                // source word of every folded column, for (fold_dim, fold_gran)
+    po_buf ws_recover;                 // integer profiles recovered from a frequency matrix (po_recover.hip)
     uint32_t fold_dim = 0, fold_gran = 0, fold_dim_f = 0, fold_dbl_at = 0;
     uint32_t* h_flag = nullptr;        // pinned host word for the fold decision
     void* h_stage[2] = {nullptr, nullptr};   // pinned staging buffers of the host-pointer entry points (device -> host rows)
@@ -104,6 +105,10 @@ int po_launch_freq_rowmajor(po_ctx* ctx, const uint32_t* d_counts, const uint64_
 // logtab (may be NULL): the JSD log table; when given, rowstat[2] = sum f ln f by the tile kernel's table log
 int po_launch_rowstat(po_ctx* ctx, const double* d_ft, uint64_t n, uint32_t dim, uint64_t npad, double* d_rowstat,
                       const void* logtab, uint32_t dbl_at);
+
+// frequency matrix -> the integer profiles it was made from, verified bit for bit (po_recover.hip)
+int po_recover_counts(po_ctx* ctx, const double* d_freq, uint64_t n, uint32_t dim, bool* recovered,
+                      const uint32_t** d_counts, const uint64_t** d_totals);
 
 // rowstat[0] (sum f ln f, when asked) and rowstat[1] (sum f) straight from integer counts: used instead of the float64
 // operand matrix + po_launch_rowstat when the equal-total kernels are known to own every tile

@@ -97,3 +97,33 @@ def test_rank_statistics_histogram_and_comparison_paths_agree(ctx):
         from_counts = ctx.pairwise(counts, totals, metric)
         from_freq = ctx.pairwise_freq(freq, metric)      # float64 input: comparison path for every record
         assert np.array_equal(from_counts, from_freq, equal_nan=True), metric
+
+
+def test_frequency_input_recovers_the_integer_profiles(ctx):
+    """po_pairwise_freq (the reference's own argument type): frequencies that are count / total are traced back to
+    the integers - verified bit for bit on the device - and take the same exact kernels as the count entry point;
+    anything else (one perturbed value is enough) runs the general float64 kernels."""
+    rng = np.random.default_rng(5)
+    counts = rng.integers(0, 60, size=(300, 256), dtype=np.uint32)
+    counts[7] = 0                                          # empty record
+    counts[8, 3:] = 0; counts[8, :3] = (2, 4, 6)           # smallest count 2: n/2 = 6 -> an equivalent reduced pair (c/2, n/2)
+    counts[9, :] = 3                                       # constant record; smallest count 3 divides the total
+    totals = counts.sum(1).astype(np.uint64)
+    freq = ctx.frequencies(counts, totals)
+    ids = {"Eucl": 4, "JSD": 6, "BC": 7, "SC": 4, "KT": 8}
+    for metric in ("Eucl", "JSD", "BC", "SC", "KT"):
+        want, st_c = ctx.pairwise(counts, totals, metric, want_stats=True)
+        got, st_f = ctx.pairwise_freq(freq, metric, want_stats=True)
+        assert st_f["kernel_id"] == st_c["kernel_id"] == ids[metric], metric
+        if metric in ("Eucl", "JSD", "BC"):
+            # record 8 is recovered as (1,2,3)/6 instead of (2,4,6)/12, and so is any record whose counts share a
+            # factor with its total: same frequencies bit for bit, same mathematics, last-bit differences at most
+            np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15, equal_nan=True)
+        else:
+            assert np.array_equal(got, want, equal_nan=True)
+    bumped = freq.copy()
+    bumped[100, 5] = np.nextafter(bumped[100, 5], 1.0)     # no longer count / total
+    for metric, general in (("Eucl", 3), ("JSD", 1), ("BC", 2)):
+        got, st = ctx.pairwise_freq(bumped, metric, want_stats=True)
+        assert st["kernel_id"] == general
+        np.testing.assert_allclose(got, ctx.pairwise_freq(freq, metric), rtol=1e-9, atol=1e-12)

@@ -175,8 +175,9 @@ def test_jsd_equal_total_table_path_and_mixed_tiles(ctx):
     seq2, off2 = pack(fixed)
     c2, t2 = ctx.count_profiles(seq2, off2, "1111", "both")
     lut = ctx.pairwise(c2, t2, "JSD")
-    gen = ctx.pairwise_freq(ctx.frequencies(c2, t2), "JSD")
+    gen = ctx.pairwise_freq(ctx.frequencies(c2, t2), "JSD", table_path=False)
     np.testing.assert_allclose(lut, gen, rtol=1e-9, atol=1e-13)
+    assert np.array_equal(ctx.pairwise_freq(ctx.frequencies(c2, t2), "JSD"), lut)      # count2freq output: traced back to the counts
     gen2, st = ctx.pairwise(c2, t2, "JSD", table_path=False, want_stats=True)
     assert st["kernel_id"] == 1 and np.array_equal(gen2, gen)
     o2c, o2t = po.compute_counts(fixed, "1111", "both")
