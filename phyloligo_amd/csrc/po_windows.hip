@@ -18,7 +18,6 @@ __global__ __launch_bounds__(256) void profile_distance_kernel(const uint32_t* _
     const uint32_t lane = threadIdx.x & 63;
     if (w >= n) return;
     const unsigned long long tot = totals[w];
-    const double inv = tot ? 1.0 / (double)tot : 0.0;
     const uint32_t* row = counts + w * dim;
     double acc = 0.0;
     for (uint32_t d = lane; d < dim; d += 64) {
@@ -37,7 +36,6 @@ __global__ __launch_bounds__(256) void profile_distance_kernel(const uint32_t* _
             acc += t;
         }
     }
-    (void)inv;
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if (lane == 0) out[w] = (metric == PO_EUCL) ? sqrt(acc) : (metric == PO_JSD ? 0.5 * acc : acc);
 }
