@@ -34,12 +34,13 @@ constexpr int KCH = 128;                            // bytes of K per record and
 constexpr int kChunkBytes = 128 * 16;               // one 16-byte K-chunk of the tile's 128 records
 constexpr int kTrStride = 33;                       // transposed 32 x 32 block of a wave, in doubles (odd: conflict free)
 constexpr int kMirrorBytes = 8 * 32 * kTrStride * 8;
-constexpr int kTermBytes = 4 * 128 * 8;             // per-record terms of the tile's rows and columns, read by the epilogue
+constexpr int kTermBytes = 6 * 128 * 8;             // per-record terms of the tile's rows and columns, read by the epilogue
 
 // planes[p][q][r][16]: digit p of words 16q..16q+15 of record r;  rs: per-record terms;  *maxabs = max |v|.
 // A workgroup takes 16 records: thread (rr = t & 15, cl = t >> 4) packs the K-chunks cl, cl+16, .. of record rr,
 // so that the 16 threads of one chunk write 256 contiguous bytes.
-//   Eucl (SIGNED = false): v = counts;  rs[0][r] = S_r / n_r^2 (S exact), rs[1][r] = 1/n_r (0 for an empty record)
+//   Eucl (SIGNED = false): v = counts;  rs[0][r] = S_r / n_r^2 (S exact), rs[1][r] = 1/n_r (0 for an empty record),
+//                                       rs[2][r] = S_r itself (an exact integer below 2^53)
 //   SC   (SIGNED = true):  v = r2;      rs[0][r] = N_r = sum r2^2 (exact)
 template <bool SIGNED>
 __global__ __launch_bounds__(256) void prep_planes_kernel(const uint32_t* __restrict__ vals,
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint32_t* __rest
             const double inv = tot ? 1.0 / (double)tot : 0.0;
             rs[r] = (double)sq_s[rr] * (inv * inv);
             rs[npad + r] = inv;
+            rs[2 * npad + r] = (double)sq_s[rr];
         }
     }
     if (t == 0) {
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
         const uint64_t rec = (t < 128) ? i0 + t : j0 + (t - 128);
         terms[t] = rs[rec];
         terms[256 + t] = METRIC == PO_EUCL ? rs[A.npad + rec] : 0.0;
+        terms[512 + t] = METRIC == PO_EUCL ? rs[2 * A.npad + rec] : 0.0;
     }
     __syncthreads();
 
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
     double* wl = reinterpret_cast<double*>(smem) + wave * (32 * kTrStride);
     const double* t0r = terms + wr * 32, *t0c = terms + 128 + wc * 64;          // Eucl: S/n^2      SC: N
     const double* t1r = terms + 256 + wr * 32, *t1c = terms + 384 + wc * 64;    // Eucl: 1/n
+    const double* t2r = terms + 512 + wr * 32, *t2c = terms + 640 + wc * 64;    // Eucl: S
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
         const uint64_t c = jw + nn * 32 + lr;
@@ -209,7 +213,16 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
             double v;
             if (METRIC == PO_EUCL) {
                 const double cross = G * (irr * ic);       // symmetric in (r,c); equals S/n^2 for duplicates
-                v = po_sqrt_nonneg(fmax((trr + tc) - 2.0 * cross, 0.0));
+                double d2 = fmax((trr + tc) - 2.0 * cross, 0.0);
+                if (d2 <= 1.0e-13 * (trr + tc)) {
+                    // cancellation level: are the two count vectors proportional, i.e. the frequency vectors identical
+                    // (distance exactly 0 in the reference)?  Cauchy-Schwarz equality G^2 == S_r S_c, tested exactly
+                    // with error-free products (all three are integers below 2^53).
+                    const double sr = t2r[rl], sc = t2c[nn * 32 + lr];
+                    const double p = G * G, pe = fma(G, G, -p), q = sr * sc, qe = fma(sr, sc, -q);
+                    if (p == q && pe == qe) d2 = 0.0;
+                }
+                v = po_sqrt_nonneg(d2);
                 if (r == c) v = 0.0;
             } else {                                       // SC; a constant record has N = 0 -> NaN as SciPy gives
                 // G / sqrt(N_r N_c) as G * rsqrt: v_rsq_f64 seed + two Newton steps (~1 ulp) instead of the
@@ -271,7 +284,7 @@ ws_view view(void* ws, uint64_t npad, uint32_t dim) {
     uint8_t* base = static_cast<uint8_t*>(ws);
     v.planes = reinterpret_cast<int8_t*>(base);
     v.rs = reinterpret_cast<double*>(base + 2 * (size_t)npad * v.dpad);
-    v.maxabs = reinterpret_cast<uint32_t*>(base + 2 * (size_t)npad * v.dpad + 2 * npad * sizeof(double));
+    v.maxabs = reinterpret_cast<uint32_t*>(base + 2 * (size_t)npad * v.dpad + 3 * npad * sizeof(double));
     return v;
 }
 
@@ -284,10 +297,10 @@ bool po_gram_i8_sc_supported(uint32_t dim) { return dim >= 1 && dim <= 8191; }  
 
 size_t po_gram_i8_workspace(uint64_t n, uint32_t dim) {
     const uint64_t npad = po_round_up(n ? n : 1, 128);
-    return 2 * npad * po_round_up(dim, KCH) + 2 * npad * sizeof(double) + 256;
+    return 2 * npad * po_round_up(dim, KCH) + 3 * npad * sizeof(double) + 256;
 }
 
-// ws layout: plane lo | plane hi | rs[2][npad] | maxabs.   signed_values: vals are int32 (SC's r2), else uint32 counts.
+// ws layout: plane lo | plane hi | rs[3][npad] | maxabs.   signed_values: vals are int32 (SC's r2), else uint32 counts.
 int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_vals, const uint64_t* d_totals, bool signed_values, uint64_t n,
                            uint32_t dim, uint64_t npad, void* ws, const uint32_t** maxabs_out) {
     const ws_view v = view(ws, npad, dim);
