@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--metric", default="JSD", choices=["Eucl", "JSD", "KT", "BC", "SC"])
     ap.add_argument("--pattern", default="1111")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 extras in config.other_configs")
     args = ap.parse_args()
 
     import torch
@@ -176,6 +177,28 @@ def main():
                          "note": "nominal roof per north_star; the tile kernels are bound by vector-ALU / LDS issue, "
                                  "not by HBM bytes, see DESIGN.md section 3"},
         }
+        if world == 1 and args.metric == "JSD" and args.contigs == 50000 and not args.no_other_configs:
+            # the other single-GPU BASELINE configurations, timed the same way (not part of `value`): C3 = the same
+            # assembly with -d Eucl, C5 = pattern 11011011 (D = 4096) with -d BC
+            others = {}
+            try:
+                def timed(c, t, metric):
+                    best = None
+                    for _ in range(3):
+                        _, st = ctx.pairwise(c, t, metric, out=slab, want_stats=True)
+                        if best is None or st["total_ms"] < best["total_ms"]:
+                            best = st
+                    return {"ms": best["total_ms"], "kernel_ms": best["kernel_ms"], "pairs_per_s": pairs / (best["total_ms"] * 1e-3),
+                            "kernel_id": best["kernel_id"], "rc_folded": best["rc_folded"]}
+                others["C3 Eucl k=4"] = timed(counts, totals, "Eucl")
+                seq5, off5 = synthetic.contig_bytes(n, args.length, seed=synthetic.SEEDS["C5"])
+                c5, t5 = ctx.count_profiles(torch.from_numpy(seq5).to(dev), torch.from_numpy(off5.astype(np.int64)).to(dev),
+                                            "11011011", "both")
+                others["C5 BC pattern 11011011"] = timed(c5, t5, "BC")
+                del c5, t5
+            except Exception as exc:             # never let the extras break the headline line
+                others["error"] = repr(exc)
+            result["config"]["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             from oracle import phyloligo_oracle as po
             freq = po.counts_to_frequencies(counts.cpu().numpy().astype(np.int64), totals.cpu().numpy())
