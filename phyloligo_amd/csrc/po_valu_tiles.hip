@@ -281,13 +281,14 @@ int po_logtab_init(po_ctx* ctx) {
 }
 
 int po_launch_valu_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const unsigned long long* cls, uint64_t* tiles) {
-    static const int rpt = getenv("PO_VALU_RPT") ? atoi(getenv("PO_VALU_RPT")) : 8;
+    // rows per lane: 4 (512 lanes per tile) measures ~2 % faster for JSD with the 512-entry log table, 8 for BC
+    static const int env_rpt = getenv("PO_VALU_RPT") ? atoi(getenv("PO_VALU_RPT")) : 0;
     if (metric == PO_JSD) {
         int rc = po_logtab_init(ctx);
         if (rc) return rc;
-        return rpt == 4 ? launch_metric<PO_JSD, 4>(ctx, a, cls, tiles) : launch_metric<PO_JSD, 8>(ctx, a, cls, tiles);
+        return env_rpt != 8 ? launch_metric<PO_JSD, 4>(ctx, a, cls, tiles) : launch_metric<PO_JSD, 8>(ctx, a, cls, tiles);
     }
-    if (metric == PO_BC) return rpt == 4 ? launch_metric<PO_BC, 4>(ctx, a, cls, tiles) : launch_metric<PO_BC, 8>(ctx, a, cls, tiles);
+    if (metric == PO_BC) return env_rpt == 4 ? launch_metric<PO_BC, 4>(ctx, a, cls, tiles) : launch_metric<PO_BC, 8>(ctx, a, cls, tiles);
     po_set_error("po_launch_valu_tiles: metric %d is not an elementwise-reduction metric", metric);
     return PO_EINVAL;
 }
