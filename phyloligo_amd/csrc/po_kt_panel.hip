@@ -73,11 +73,11 @@ __global__ __launch_bounds__(kThreads, 4) void kt_panel_tile_kernel(po_tile_args
 
     for (uint32_t i = t; i < n_diag_items; i += kThreads) litems[i] = diag_items[i];
 
-    v16i g[2], gt[2];
+    v16i g[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { g[m][e] = 0; gt[m][e] = 0; }
+        for (int e = 0; e < 16; ++e) g[m][e] = 0;
 
     uint32_t one2, mone2;
     asm volatile("v_mov_b32 %0, 0x00010001" : "=v"(one2));
@@ -169,7 +169,6 @@ __global__ __launch_bounds__(kThreads, 4) void kt_panel_tile_kernel(po_tile_args
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 g[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks][m], b[ks], g[m], 0, 0, 0);
-                if (mirror) gt[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[ks], a[ks][m], gt[m], 0, 0, 0);
             }
         }
     };
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(kThreads, 4) void kt_panel_tile_kernel(po_tile_args
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { g[m][e] <<= 1; gt[m][e] <<= 1; }
+            for (int e = 0; e < 16; ++e) g[m][e] <<= 1;
     };
 
     const uint32_t n_panels = (words + PW - 1) / PW;
@@ -224,37 +223,50 @@ __global__ __launch_bounds__(kThreads, 4) void kt_panel_tile_kernel(po_tile_args
     if (producer) return;
 
     // ---- epilogue: tau = S / sqrt((T - t_r)(T - t_c)), KT = 1 - (1 - tau), 0 when a factor vanishes -----
+    // the mirrored tile is transposed through wave-private LDS (rank panels and sign tiles are no longer needed:
+    // the last round ended with a barrier)
     const double T = 0.5 * (double)dim_full * ((double)dim_full - 1.0);
     const double* ties = A.rowstat + 3 * A.npad;
-    auto emit = [&](const v16i& acc, uint64_t r0, uint64_t c0, bool swap) {
-        OUT* dst = static_cast<OUT*>(swap ? A.mirror : A.out);
-        const uint64_t ld = swap ? A.ld_mirror : A.ld_out;
-        const uint64_t row_off = swap ? A.col_begin : A.row_begin, col_off = swap ? A.row_begin : A.col_begin;
-        const uint64_t row_hi = min(A.n, swap ? A.col_end : A.row_end), col_hi = min(A.n, swap ? A.row_end : A.col_end);
-        const uint64_t c = c0 + lr;
-        const double dc = T - ties[min(c, A.npad - 1)];
-        double drs[16];                                    // every load before the first store (shared in-order vmcnt)
+    OUT* out = static_cast<OUT*>(A.out);
+    OUT* mir = static_cast<OUT*>(A.mirror);
+    const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
+    const uint64_t ri = i0 + wr * 64, cj = j0 + wc * 32;
+    double* wl = reinterpret_cast<double*>(smem) + cw_ * (32 * 33);            // 8 consumer waves x 8.4 KiB
+    const uint64_t c = cj + lr;
+    const double dc = T - ties[min(c, A.npad - 1)];
+    double drs[2][16];                                     // every load before the first store (shared in-order vmcnt)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) drs[reg] = T - ties[min(r0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh, A.npad - 1)];
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) drs[m][reg] = T - ties[min(ri + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh, A.npad - 1)];
+    const bool c_ok = c >= A.col_begin && c < n_cols;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const uint64_t rr = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            const double dr = drs[reg];
+            const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            const uint64_t rr = ri + m * 32 + rl;
+            const double dr = drs[m][reg];
             double v;
             if (dr == 0.0 || dc == 0.0) {
                 v = 1.0 - 1.0;
             } else {
-                const double tau = (double)acc[reg] / sqrt(dr * dc);
+                const double tau = (double)g[m][reg] / sqrt(dr * dc);
                 v = 1.0 - (1.0 - tau);
             }
-            if (rr >= row_off && rr < row_hi && c >= col_off && c < col_hi) dst[(rr - row_off) * ld + (c - col_off)] = (OUT)v;
+            if (c_ok && rr >= A.row_begin && rr < n_rows) out[(rr - A.row_begin) * A.ld_out + (c - A.col_begin)] = (OUT)v;
+            if (mirror) wl[lr * 33 + rl] = v;
         }
-    };
-    const uint64_t ri = i0 + wr * 64, cj = j0 + wc * 32;
+        if (mirror) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        emit(g[m], ri + m * 32, cj, false);
-        if (mirror) emit(gt[m], cj, ri + m * 32, true);
+            for (int it = 0; it < 16; ++it) {
+                const uint32_t jr = it * 2 + lh;
+                const double w = wl[jr * 33 + lr];
+                const uint64_t cm = cj + jr, rr = ri + m * 32 + lr;
+                if (cm >= A.col_begin && cm < n_cols && rr >= A.row_begin && rr < n_rows)
+                    mir[(cm - A.col_begin) * A.ld_mirror + (rr - A.row_begin)] = (OUT)w;
+            }
+        }
     }
 }
 
