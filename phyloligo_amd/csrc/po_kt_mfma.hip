@@ -23,6 +23,8 @@
 // 704 items instead of 2 160 at D = 256 (49 ms).
 #include "po_tiles.h"
 
+#include <stdlib.h>
+
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -30,9 +32,14 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef short v2s __attribute__((ext_vector_type(2)));
 
 constexpr int TM = 128, TN = 128;
-constexpr int kThreads = 1024;              // waves 0-7 expand signs (two lanes per record), waves 8-15 run the MFMAs
-constexpr int KS = 4;                       // K steps (32 word pairs each) per barrier
-constexpr int kSigStride = KS * 32 + 16;    // bytes per record in the sign tile (+16: conflict-free b128 rows)
+constexpr int kThreads = 1024;              // 16 waves: PWAVES of them expand signs, the others run the MFMAs
+constexpr int KS = 4;                       // items (16 word pairs each) per producer lane and round
+// Two splits of the workgroup.  PWAVES = 8: two lanes per record expand 8 items per round (4 K-steps of 32 word
+// pairs), 8 consumer waves of 64 x 32 outputs.  PWAVES = 12 (when the rank rows are short enough for the larger
+// sign tiles to fit LDS, e.g. folded k = 4): three lanes per record expand 12 items per round (6 K-steps), 4
+// consumer waves of 64 x 64 outputs - the kernel is paced by the sign expansion, so more of the lanes go there.
+__host__ __device__ constexpr int kt_ksteps(int pwaves) { return pwaves == 8 ? 4 : 6; }
+__host__ __device__ constexpr int kt_sig_stride(int pwaves) { return kt_ksteps(pwaves) * 32 + 16; }   // +16: conflict-free b128 rows
 
 // rank8[r][c] = (uint8) lessrank[r][src ? src[c] : c], rows of `row_bytes` columns (zero beyond the words / records).
 // src = the folded column order of po_fold.hip: ranks among all D words keep the order and ties of the kept words.
@@ -59,13 +66,16 @@ __device__ __forceinline__ uint32_t sign4(uint32_t w, uint32_t xp2, uint32_t one
     return __builtin_amdgcn_perm(hi, lo, 0x06020400u);
 }
 
-template <typename OUT>
+template <typename OUT, int PWAVES>
 __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args A, const uint8_t* __restrict__ rank8,
                                                                    const uint16_t* __restrict__ items, uint32_t n_items,
                                                                    uint32_t row_bytes, uint32_t dim_full, uint32_t dbl1,
                                                                    uint32_t dbl2) {
     // A.dim = number of words the items range over (the folded count when dbl1/dbl2 are set), row_bytes = length of a
     // rank row in memory (a multiple of 16 or A.dim), dim_full = D of the records (tie algebra of the epilogue).
+    constexpr int KSV = kt_ksteps(PWAVES), kSigStride = kt_sig_stride(PWAVES);
+    constexpr int NB = PWAVES == 8 ? 1 : 2;                            // 32-column blocks per consumer wave
+    constexpr int CH = PWAVES == 8 ? 4 : 3;                            // K-steps whose fragments are in flight at once
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t rstride = row_bytes + 16;                           // rank row stride in LDS (bytes)
     unsigned char* ranks = smem;                                       // [256][rstride]
@@ -74,9 +84,10 @@ __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args 
 
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & 63, wave = t >> 6;
-    const bool producer = wave < 8;                                    // wave-uniform role
-    const uint32_t cw_ = wave & 7, wr = cw_ >> 2, wc = cw_ & 3;        // consumer wave -> 64 rows x 32 columns of the tile
-    const uint32_t half = __builtin_amdgcn_readfirstlane(t >> 8) & 1;  // producer wave: which half of a round's items (uniform)
+    const bool producer = wave < PWAVES;                               // wave-uniform role
+    const uint32_t cw_ = producer ? 0u : wave - PWAVES;                // consumer wave -> 64 rows x 32 NB columns of the tile
+    const uint32_t wr = PWAVES == 8 ? cw_ >> 2 : cw_ >> 1, wc = PWAVES == 8 ? cw_ & 3 : cw_ & 1;
+    const uint32_t half = __builtin_amdgcn_readfirstlane(t >> 8) & 3;  // producer wave: which part of a round's items (uniform)
     const uint32_t lr = lane & 31, lh = lane >> 5;
 
     uint32_t ti, tj;
@@ -99,11 +110,13 @@ __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args 
     for (uint32_t i = t; i < n_items; i += kThreads) litems[i] = items[i];
     __syncthreads();
 
-    v16i g[2];
+    v16i g[2][NB];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) g[m][e] = 0;
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) g[m][nb][e] = 0;
 
     // sign expansion of KS K-steps (2 items each) for this lane's record into sign buffer `buf`.
     // MASKED = false for the rounds whose 16-q blocks lie entirely above their p (no byte to suppress).
@@ -154,23 +167,27 @@ __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args 
         }
     };
 
-    const uint32_t n_rounds = n_items / (2 * KS);                       // items are padded to a multiple of 2 KS
+    const uint32_t n_rounds = n_items / (2 * KSV);                      // items are padded to whole rounds of 2 KSV
     auto consume = [&](uint32_t buf) {
         const unsigned char* sa = sigma + (buf * 256 + wr * 64 + lr) * kSigStride + 16 * lh;
-        const unsigned char* sb = sigma + (buf * 256 + 128 + wc * 32 + lr) * kSigStride + 16 * lh;
-        v4i a[KS][2], b[KS];                                           // all fragment reads of the round in flight at once
+        const unsigned char* sb = sigma + (buf * 256 + 128 + wc * 32 * NB + lr) * kSigStride + 16 * lh;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int k0 = 0; k0 < KSV; k0 += CH) {
+            v4i a[CH][2], b[CH][NB];                                   // the fragment reads of CH K-steps in flight at once
 #pragma unroll
-            for (int m = 0; m < 2; ++m) a[ks][m] = *reinterpret_cast<const v4i*>(sa + m * 32 * kSigStride + ks * 32);
-            b[ks] = *reinterpret_cast<const v4i*>(sb + ks * 32);
-        }
+            for (int ks = 0; ks < CH; ++ks) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+                for (int m = 0; m < 2; ++m) a[ks][m] = *reinterpret_cast<const v4i*>(sa + m * 32 * kSigStride + (k0 + ks) * 32);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                g[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks][m], b[ks], g[m], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) b[ks][nb] = *reinterpret_cast<const v4i*>(sb + nb * 32 * kSigStride + (k0 + ks) * 32);
             }
+#pragma unroll
+            for (int ks = 0; ks < CH; ++ks)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        g[m][nb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks][m], b[ks][nb], g[m][nb], 0, 0, 0);
         }
     };
     // rounds [0, n_full_rounds) hold only whole blocks (no masking code in the hot loop), the rest may be partial.
@@ -183,14 +200,16 @@ __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args 
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) g[m][e] <<= 1;
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) g[m][nb][e] <<= 1;
     };
     if (producer) expand(0, 0);
     __syncthreads();
     for (uint32_t r = 0; r < n_rounds; ++r) {
         const uint32_t buf = r & 1;
         if (producer) {
-            if (r + 1 < n_rounds) expand((r + 1) * 2 * KS, buf ^ 1);
+            if (r + 1 < n_rounds) expand((r + 1) * 2 * KSV, buf ^ 1);
         } else {
             if (r == dbl1) double_sums();
             if (r == dbl2) double_sums();
@@ -210,41 +229,47 @@ __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args 
     OUT* out = static_cast<OUT*>(A.out);
     OUT* mir = static_cast<OUT*>(A.mirror);
     const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
-    const uint64_t ri = i0 + wr * 64, cj = j0 + wc * 32;
-    double* wl = reinterpret_cast<double*>(smem) + cw_ * (32 * 33);            // 8 consumer waves x 8.4 KiB
-    const uint64_t c = cj + lr;
-    const double dc = T - ties[min(c, A.npad - 1)];
+    const uint64_t ri = i0 + wr * 64, cj = j0 + wc * 32 * NB;
+    double* wl = reinterpret_cast<double*>(smem) + cw_ * (32 * 33);            // one 8.4 KiB scratch per consumer wave
     double drs[2][16];                                     // every load before the first store (shared in-order vmcnt)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) drs[m][reg] = T - ties[min(ri + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh, A.npad - 1)];
-    const bool c_ok = c >= A.col_begin && c < n_cols;
+    double dcs[NB];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int nb = 0; nb < NB; ++nb) dcs[nb] = T - ties[min(cj + nb * 32 + lr, A.npad - 1)];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            const uint64_t rr = ri + m * 32 + rl;
-            const double dr = drs[m][reg];
-            double v;
-            if (dr == 0.0 || dc == 0.0) {
-                v = 1.0 - 1.0;
-            } else {
-                const double tau = (double)g[m][reg] / sqrt(dr * dc);
-                v = 1.0 - (1.0 - tau);
+    for (int nb = 0; nb < NB; ++nb) {
+        const uint64_t c = cj + nb * 32 + lr;
+        const double dc = dcs[nb];
+        const bool c_ok = c >= A.col_begin && c < n_cols;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                const uint64_t rr = ri + m * 32 + rl;
+                const double dr = drs[m][reg];
+                double v;
+                if (dr == 0.0 || dc == 0.0) {
+                    v = 1.0 - 1.0;
+                } else {
+                    const double tau = (double)g[m][nb][reg] / sqrt(dr * dc);
+                    v = 1.0 - (1.0 - tau);
+                }
+                if (c_ok && rr >= A.row_begin && rr < n_rows) out[(rr - A.row_begin) * A.ld_out + (c - A.col_begin)] = (OUT)v;
+                if (mirror) wl[lr * 33 + rl] = v;
             }
-            if (c_ok && rr >= A.row_begin && rr < n_rows) out[(rr - A.row_begin) * A.ld_out + (c - A.col_begin)] = (OUT)v;
-            if (mirror) wl[lr * 33 + rl] = v;
-        }
-        if (mirror) {                                      // LDS operations of one wave execute in order
+            if (mirror) {                                  // LDS operations of one wave execute in order
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const uint32_t jr = it * 2 + lh;
-                const double w = wl[jr * 33 + lr];
-                const uint64_t cm = cj + jr, rr = ri + m * 32 + lr;
-                if (cm >= A.col_begin && cm < n_cols && rr >= A.row_begin && rr < n_rows)
-                    mir[(cm - A.col_begin) * A.ld_mirror + (rr - A.row_begin)] = (OUT)w;
+                for (int it = 0; it < 16; ++it) {
+                    const uint32_t jr = it * 2 + lh;
+                    const double w = wl[jr * 33 + lr];
+                    const uint64_t cm = cj + nb * 32 + jr, rr = ri + m * 32 + lr;
+                    if (cm >= A.col_begin && cm < n_cols && rr >= A.row_begin && rr < n_rows)
+                        mir[(cm - A.col_begin) * A.ld_mirror + (rr - A.row_begin)] = (OUT)w;
+                }
             }
         }
     }
@@ -269,6 +294,13 @@ int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, 
                            const uint32_t* fold_src, uint32_t n_selfs, uint32_t n_pairs, po_kt_mfma_plan* plan) {
     const uint32_t words = fold_src ? n_selfs + n_pairs : dim;        // words the items range over
     const uint32_t row_bytes = fold_src ? (uint32_t)po_round_up(words, 16) : dim;
+    // 12 producer waves are possible when the larger sign tiles still fit the 160 KiB of LDS next to the rank rows;
+    // measured at N = 50 000, folded k = 4: 48.5 ms against 45.5 ms with 8 - the kernel is paced by its barriers and
+    // LDS round trips, not by the number of expanding lanes - so 8 is the default and PO_KT_PWAVES=12 the experiment.
+    static const bool want12 = getenv("PO_KT_PWAVES") && atoi(getenv("PO_KT_PWAVES")) == 12;
+    const bool fits12 = 256 * (size_t)(row_bytes + 16) + 2 * 256 * (size_t)kt_sig_stride(12) + 4096 <= 160 * 1024;
+    const int pwaves = (want12 && fits12) ? 12 : 8;
+    const uint32_t round_items = 2 * (uint32_t)kt_ksteps(pwaves);
     uint8_t* rank8 = static_cast<uint8_t*>(ws);
     uint16_t* d_items = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(ws) + ((npad * row_bytes + 255) & ~(uint64_t)255));
     hipLaunchKernelGGL(rank8_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_lessrank, n, dim, npad, fold_src, row_bytes, rank8);
@@ -283,7 +315,7 @@ int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, 
     const int n_classes = fold_src ? 3 : 1;
     for (int cls = 0; cls < n_classes; ++cls) {
         const uint32_t want = fold_src ? (4u >> cls) : 0u;             // 4, 2, 1
-        class_start[cls] = cnt / (2 * KS);
+        class_start[cls] = cnt / round_items;
         for (int partial = 0; partial < 2; ++partial)
             for (uint32_t p = 0; p + 1 < words; ++p)
                 for (uint32_t qb = (p + 1) / 16; qb < nblk; ++qb) {
@@ -294,15 +326,16 @@ int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, 
                     const bool whole = qb * 16 > p && qb * 16 + 16 <= words;
                     if (whole == (partial == 0)) host_items[cnt++] = (uint16_t)((p << 8) | (whole ? 0u : 0x80u) | qb);
                 }
-        while (cnt % (2 * KS)) host_items[cnt++] = (uint16_t)(((words - 1) << 8) | 0x80u);   // fully masked padding
+        while (cnt % round_items) host_items[cnt++] = (uint16_t)(((words - 1) << 8) | 0x80u);   // fully masked padding
     }
-    while (cnt == 0) for (int i = 0; i < 2 * KS; ++i) host_items[cnt++] = (uint16_t)(((words - 1) << 8) | 0x80u);
-    class_start[n_classes] = cnt / (2 * KS);
+    while (cnt == 0) for (uint32_t i = 0; i < round_items; ++i) host_items[cnt++] = (uint16_t)(((words - 1) << 8) | 0x80u);
+    class_start[n_classes] = cnt / round_items;
     PO_HIP(hipMemcpyAsync(d_items, host_items, cnt * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
     PO_HIP(hipStreamSynchronize(ctx->stream));                        // host_items is reused by the next call
     plan->n_items = cnt;
     plan->words = words;
     plan->row_bytes = row_bytes;
+    plan->pwaves = (uint32_t)pwaves;
     plan->dbl1 = fold_src ? class_start[1] : PO_NO_DOUBLING;          // == number of rounds when the later classes are empty
     plan->dbl2 = fold_src ? class_start[2] : PO_NO_DOUBLING;
     return PO_OK;
@@ -318,18 +351,18 @@ int po_launch_kt_mfma_tiles(po_ctx* ctx, const po_tile_args& a_in, const void* w
     if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
-    const size_t shmem = ((256 * (plan.row_bytes + 16) + 15) & ~(size_t)15) + 2 * 256 * kSigStride + ((plan.n_items * 2 + 15) & ~(size_t)15);
-    if (a.out_f32) {
-        auto k = kt_mfma_tile_kernel<float>;
+    const size_t shmem = ((256 * (plan.row_bytes + 16) + 15) & ~(size_t)15) + 2 * 256 * (size_t)kt_sig_stride((int)plan.pwaves) +
+                         ((plan.n_items * 2 + 15) & ~(size_t)15);
+    auto launch = [&](auto k) -> int {
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, rank8, d_items, plan.n_items,
                            plan.row_bytes, dim_full, plan.dbl1, plan.dbl2);
-    } else {
-        auto k = kt_mfma_tile_kernel<double>;
-        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, rank8, d_items, plan.n_items,
-                           plan.row_bytes, dim_full, plan.dbl1, plan.dbl2);
-    }
+        return PO_OK;
+    };
+    int lrc;
+    if (plan.pwaves == 12) lrc = a.out_f32 ? launch(kt_mfma_tile_kernel<float, 12>) : launch(kt_mfma_tile_kernel<double, 12>);
+    else lrc = a.out_f32 ? launch(kt_mfma_tile_kernel<float, 8>) : launch(kt_mfma_tile_kernel<double, 8>);
+    if (lrc) return lrc;
     PO_CHECK_LAUNCH("kt_mfma_tile_kernel");
     return PO_OK;
 }
