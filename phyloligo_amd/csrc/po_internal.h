@@ -185,6 +185,7 @@ size_t po_kt_mfma_workspace(uint64_t n, uint32_t dim);
 struct po_kt_mfma_plan {
     uint32_t n_items, words, row_bytes, dbl1, dbl2;
     uint32_t pwaves;        // producer waves of the 16-wave workgroup: 8 or 12
+    uint32_t ksteps;        // K-steps of 32 word pairs per round (per workgroup barrier): 4 or 6
 };
 int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, uint64_t npad, void* ws,
                            const uint32_t* fold_src, uint32_t n_selfs, uint32_t n_pairs, po_kt_mfma_plan* plan);

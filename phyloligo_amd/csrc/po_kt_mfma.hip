@@ -33,13 +33,13 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 
 constexpr int TM = 128, TN = 128;
 constexpr int kThreads = 1024;              // 16 waves: PWAVES of them expand signs, the others run the MFMAs
-constexpr int KS = 4;                       // items (16 word pairs each) per producer lane and round
 // Two splits of the workgroup.  PWAVES = 8: two lanes per record expand 8 items per round (4 K-steps of 32 word
 // pairs), 8 consumer waves of 64 x 32 outputs.  PWAVES = 12 (when the rank rows are short enough for the larger
 // sign tiles to fit LDS, e.g. folded k = 4): three lanes per record expand 12 items per round (6 K-steps), 4
 // consumer waves of 64 x 64 outputs - the kernel is paced by the sign expansion, so more of the lanes go there.
-__host__ __device__ constexpr int kt_ksteps(int pwaves) { return pwaves == 8 ? 4 : 6; }
-__host__ __device__ constexpr int kt_sig_stride(int pwaves) { return kt_ksteps(pwaves) * 32 + 16; }   // +16: conflict-free b128 rows
+// KSV = K-steps (32 word pairs = 2 items each) per round, i.e. per workgroup barrier: 4 (sign tiles of 2 x 36 KiB) or,
+// when the rank rows leave room in LDS, 6 (2 x 52 KiB) - fewer barriers per tile.
+__host__ __device__ constexpr int kt_sig_stride(int ksv) { return ksv * 32 + 16; }   // +16: conflict-free b128 rows
 
 // rank8[r][c] = (uint8) lessrank[r][src ? src[c] : c], rows of `row_bytes` columns (zero beyond the words / records).
 // src = the folded column order of po_fold.hip: ranks among all D words keep the order and ties of the kept words.
@@ -66,16 +66,17 @@ __device__ __forceinline__ uint32_t sign4(uint32_t w, uint32_t xp2, uint32_t one
     return __builtin_amdgcn_perm(hi, lo, 0x06020400u);
 }
 
-template <typename OUT, int PWAVES>
+template <typename OUT, int PWAVES, int KSV>
 __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args A, const uint8_t* __restrict__ rank8,
                                                                    const uint16_t* __restrict__ items, uint32_t n_items,
                                                                    uint32_t row_bytes, uint32_t dim_full, uint32_t dbl1,
                                                                    uint32_t dbl2) {
     // A.dim = number of words the items range over (the folded count when dbl1/dbl2 are set), row_bytes = length of a
     // rank row in memory (a multiple of 16 or A.dim), dim_full = D of the records (tie algebra of the epilogue).
-    constexpr int KSV = kt_ksteps(PWAVES), kSigStride = kt_sig_stride(PWAVES);
+    constexpr int kSigStride = kt_sig_stride(KSV);
+    constexpr int KS = 2 * KSV / (PWAVES / 4);                         // items per producer lane and round (4 or 6)
     constexpr int NB = PWAVES == 8 ? 1 : 2;                            // 32-column blocks per consumer wave
-    constexpr int CH = PWAVES == 8 ? 4 : 3;                            // K-steps whose fragments are in flight at once
+    constexpr int CH = (PWAVES == 8 && KSV == 4) ? 4 : 3;              // K-steps whose fragments are in flight at once
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t rstride = row_bytes + 16;                           // rank row stride in LDS (bytes)
     unsigned char* ranks = smem;                                       // [256][rstride]
@@ -127,9 +128,14 @@ __global__ __launch_bounds__(kThreads, 4) void kt_mfma_tile_kernel(po_tile_args 
     auto expand = [&](uint32_t item0, uint32_t buf) {
         unsigned char* dst = sigma + (buf * 256 + (t & 255)) * kSigStride;
         // this wave's KS item codes (wave uniform -> scalar registers): (p << 8) | partial flag (bit 7) | q block
-        const uint2 c2 = *reinterpret_cast<const uint2*>(litems + item0 + half * KS);
-        const uint32_t cw[2] = {(uint32_t)__builtin_amdgcn_readfirstlane(c2.x), (uint32_t)__builtin_amdgcn_readfirstlane(c2.y)};
-        const bool masked = ((cw[0] | cw[1]) & 0x00800080u) != 0u;     // blocks lying wholly above their p need no masking
+        uint32_t cw[KS / 2];
+        uint32_t flags = 0;
+#pragma unroll
+        for (int i = 0; i < KS / 2; ++i) {
+            cw[i] = (uint32_t)__builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t*>(litems + item0 + half * KS)[i]);
+            flags |= cw[i];
+        }
+        const bool masked = (flags & 0x00800080u) != 0u;               // blocks lying wholly above their p need no masking
         // all LDS reads of the lane's KS items first (the sign-tile stores below may alias them for the
         // compiler, which would otherwise serialise read -> compute -> store item by item)
         uint32_t pp[KS], qq[KS], xps[KS];
@@ -294,13 +300,16 @@ int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, 
                            const uint32_t* fold_src, uint32_t n_selfs, uint32_t n_pairs, po_kt_mfma_plan* plan) {
     const uint32_t words = fold_src ? n_selfs + n_pairs : dim;        // words the items range over
     const uint32_t row_bytes = fold_src ? (uint32_t)po_round_up(words, 16) : dim;
-    // 12 producer waves are possible when the larger sign tiles still fit the 160 KiB of LDS next to the rank rows;
-    // measured at N = 50 000, folded k = 4: 48.5 ms against 45.5 ms with 8 - the kernel is paced by its barriers and
-    // LDS round trips, not by the number of expanding lanes - so 8 is the default and PO_KT_PWAVES=12 the experiment.
+    // Rounds of 4 K-steps and 8 expanding waves are the default.  Both alternatives were built and measured at
+    // N = 50 000, folded k = 4 (45.2 ms): 6 K-steps per round (fewer barriers, needs the larger sign tiles to fit LDS)
+    // 46.2 ms, 12 expanding waves 48.5 ms - neither the barrier count nor the number of expanding lanes paces
+    // the kernel.  They stay selectable for experiments: PO_KT_KSTEPS=6, PO_KT_PWAVES=12.
     static const bool want12 = getenv("PO_KT_PWAVES") && atoi(getenv("PO_KT_PWAVES")) == 12;
-    const bool fits12 = 256 * (size_t)(row_bytes + 16) + 2 * 256 * (size_t)kt_sig_stride(12) + 4096 <= 160 * 1024;
-    const int pwaves = (want12 && fits12) ? 12 : 8;
-    const uint32_t round_items = 2 * (uint32_t)kt_ksteps(pwaves);
+    static const bool want6 = want12 || (getenv("PO_KT_KSTEPS") && atoi(getenv("PO_KT_KSTEPS")) == 6);
+    const bool fits6 = 256 * (size_t)(row_bytes + 16) + 2 * 256 * (size_t)kt_sig_stride(6) + 4096 <= 160 * 1024;
+    const int ksv = (fits6 && want6) ? 6 : 4;
+    const int pwaves = (want12 && ksv == 6) ? 12 : 8;
+    const uint32_t round_items = 2 * (uint32_t)ksv;
     uint8_t* rank8 = static_cast<uint8_t*>(ws);
     uint16_t* d_items = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(ws) + ((npad * row_bytes + 255) & ~(uint64_t)255));
     hipLaunchKernelGGL(rank8_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_lessrank, n, dim, npad, fold_src, row_bytes, rank8);
@@ -336,6 +345,7 @@ int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, 
     plan->words = words;
     plan->row_bytes = row_bytes;
     plan->pwaves = (uint32_t)pwaves;
+    plan->ksteps = (uint32_t)ksv;
     plan->dbl1 = fold_src ? class_start[1] : PO_NO_DOUBLING;          // == number of rounds when the later classes are empty
     plan->dbl2 = fold_src ? class_start[2] : PO_NO_DOUBLING;
     return PO_OK;
@@ -351,7 +361,7 @@ int po_launch_kt_mfma_tiles(po_ctx* ctx, const po_tile_args& a_in, const void* w
     if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
-    const size_t shmem = ((256 * (plan.row_bytes + 16) + 15) & ~(size_t)15) + 2 * 256 * (size_t)kt_sig_stride((int)plan.pwaves) +
+    const size_t shmem = ((256 * (plan.row_bytes + 16) + 15) & ~(size_t)15) + 2 * 256 * (size_t)kt_sig_stride((int)plan.ksteps) +
                          ((plan.n_items * 2 + 15) & ~(size_t)15);
     auto launch = [&](auto k) -> int {
         PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -360,8 +370,9 @@ int po_launch_kt_mfma_tiles(po_ctx* ctx, const po_tile_args& a_in, const void* w
         return PO_OK;
     };
     int lrc;
-    if (plan.pwaves == 12) lrc = a.out_f32 ? launch(kt_mfma_tile_kernel<float, 12>) : launch(kt_mfma_tile_kernel<double, 12>);
-    else lrc = a.out_f32 ? launch(kt_mfma_tile_kernel<float, 8>) : launch(kt_mfma_tile_kernel<double, 8>);
+    if (plan.pwaves == 12) lrc = a.out_f32 ? launch(kt_mfma_tile_kernel<float, 12, 6>) : launch(kt_mfma_tile_kernel<double, 12, 6>);
+    else if (plan.ksteps == 6) lrc = a.out_f32 ? launch(kt_mfma_tile_kernel<float, 8, 6>) : launch(kt_mfma_tile_kernel<double, 8, 6>);
+    else lrc = a.out_f32 ? launch(kt_mfma_tile_kernel<float, 8, 4>) : launch(kt_mfma_tile_kernel<double, 8, 4>);
     if (lrc) return lrc;
     PO_CHECK_LAUNCH("kt_mfma_tile_kernel");
     return PO_OK;
