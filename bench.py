@@ -2,15 +2,23 @@
 """Headline benchmark: contig-pairs/sec of the all-by-all distance matrix (BASELINE.json).
 
 A step = one pass of stage 2 (counts resident in HBM -> every matrix entry of this rank's shard
-resident in HBM, float64) over one synthetic assembly.  N=1: BASELINE config 2, 50,000 contigs x
-2 kb, k=4, both strands, -d JSD.  N>1: one process per GPU (torch.distributed, RCCL), the count
-matrix is all-gathered once, then the upper triangle of the block grid is dealt out tournament-style
-(phyloligo_amd/dist.py) so that every pair is evaluated once, with no further exchange inside the timed
-region; the assembly grows as 50,000*sqrt(N) contigs so that the pairs per GPU stay fixed (weak scaling).
+resident in HBM, float64) over one synthetic assembly.
+
+  --gpus 1   BASELINE config 2: 50 000 contigs x 2 kb (seed 50001), k=4, both strands, -d JSD.
+  --gpus N>1 BASELINE config 4: 200 000 contigs x 2 kb (seed 200001), k=4, -d JSD, row-block sharded: one
+             process per GPU (torch.distributed, RCCL); every rank profiles its own contigs, the exact count
+             matrix is all-gathered ONCE, then the upper triangle of the block grid is dealt out tournament-style
+             (phyloligo_amd/dist.py) so that every pair is evaluated once, with no exchange inside the timed
+             region.  The matrix (320 GB in float64) does not fit one GPU, which is why N=1 runs config 2; the
+             work is the same for N = 2, 4, 8 ("strong" scaling), and pairs/s is comparable across all N.
+
+Beside `value` the JSON line carries: the roofline of the dominant kernel (HIP-event time on the launch stream),
+the same for the other single-GPU BASELINE configs (C3 Eucl on both its paths, C5 BC) and for the general JSD
+kernel that ragged assemblies get, the CPU baseline (oracle = the reference's joblib path restated) and, for N>1,
+the times of the single exchange (all-gather) and of the optional row-completing exchange.
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -21,24 +29,75 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable by a float4 copy)
+F64_MFMA_PEAK_TF = 78.6   # v_mfma_f64_16x16x4_f64 dense peak
+
+KERNEL_NAMES = {1: "valu_tile_kernel<JSD>", 2: "valu_tile_kernel<BC>", 3: "gram_tile_kernel (f64 MFMA)",
+                4: "gram_i8_tile_kernel (exact int8 MFMA)", 5: "kt_tile_kernel",
+                6: "jsd_lut_tile_kernel (equal-total record blocks) + valu_tile_kernel<JSD> (rest)",
+                7: "bc_sad_tile_kernel (equal-total record blocks) + valu_tile_kernel<BC> (rest)",
+                8: "pairdot_tile_kernel<KT> (materialised pair-sign Gram on the matrix cores)",
+                9: "pairdot_tile_kernel<BC> (thermometer planes: sum of min on the matrix cores)"}
 
 
-def cpu_baseline_jsd(freq, metric, budget_rows):
-    """The oracle's per-pair Python path (= the reference's joblib path: one metric call per
-    pair under sklearn.pairwise_distances) timed on a bounded slab of rows x all columns."""
+def _oracle_rows(freq, metric, rows):
+    from oracle import phyloligo_oracle as po
+    return po.pairwise_rows(freq, metric, rows).shape
+
+
+def _oracle_profiles(seqs):
+    from oracle import phyloligo_oracle as po
+    return po.compute_frequencies(seqs, "1111", "both")
+
+
+def cpu_baseline(freq, metric, budget_s=12.0):
+    """The oracle's per-pair Python path (= the reference's joblib path: one metric call per pair under
+    sklearn.pairwise_distances, phyloligo.py:364-392) on os.cpu_count() processes.
+    (1) a bounded slab of rows x all columns of THIS workload; (2) BASELINE config 1 in full (1 000 contigs, Eucl:
+    Counter-style profiles + 10^6 metric calls), as SURVEY 8d asks."""
     import joblib
     from oracle import phyloligo_oracle as po
-    cores = min(os.cpu_count() or 1, 16)
-    rows_per = max(1, budget_rows // cores)
-    slabs = [list(range(c * rows_per, (c + 1) * rows_per)) for c in range(cores)]
+    cores = os.cpu_count() or 1
+    n = freq.shape[0]
+    # probe the per-call cost on one core, then size the slab to ~budget_s of wall time on all cores
     t0 = time.perf_counter()
-    joblib.Parallel(n_jobs=cores)(joblib.delayed(po.pairwise_rows)(freq, metric, rows) for rows in slabs)
-    dt = time.perf_counter() - t0
-    evaluated = cores * rows_per * freq.shape[0]
-    return {"value": evaluated / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d rows x %d columns = %d metric calls of oracle.%s (per-pair numpy path of "
-                      "phylodist.py) in %.1f s over %d processes" % (cores * rows_per, freq.shape[0], evaluated, metric, dt, cores)}
+    po.pairwise_rows(freq[:2000], metric, [0])
+    per_call = (time.perf_counter() - t0) / min(n, 2000)
+    rows_per = max(1, int(budget_s / max(per_call * n, 1e-9)))
+    rows_per = min(rows_per, 64, max(1, n // cores))
+    slabs = [list(range(c * rows_per, (c + 1) * rows_per)) for c in range(cores) if (c + 1) * rows_per <= n]
+    with joblib.Parallel(n_jobs=cores) as par:
+        par(joblib.delayed(_oracle_rows)(freq[:8], metric, [0]) for _ in range(cores))          # start the workers
+        t0 = time.perf_counter()
+        par(joblib.delayed(_oracle_rows)(freq, metric, rows) for rows in slabs)
+        dt = time.perf_counter() - t0
+        evaluated = len(slabs) * rows_per * n
+        out = {"value": evaluated / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+               "sample": "%d rows x %d columns = %d metric calls of oracle.%s (per-pair numpy path of phylodist.py under "
+                         "sklearn.pairwise_distances semantics) in %.1f s over %d processes"
+                         % (len(slabs) * rows_per, n, evaluated, metric, dt, cores)}
+        # ---- BASELINE config 1, whole: 1 000 contigs x 2 kb, k=4 both strands, -d Eucl ----
+        seqs = po.synthetic_contigs(1000, 2000, seed=1001)
+        per = -(-len(seqs) // cores)
+        t0 = time.perf_counter()
+        parts = par(joblib.delayed(_oracle_profiles)(seqs[c * per:(c + 1) * per]) for c in range(cores) if seqs[c * per:(c + 1) * per])
+        f1 = np.vstack(parts)
+        t_prof = time.perf_counter() - t0
+        per = -(-1000 // cores)
+        t0 = time.perf_counter()
+        par(joblib.delayed(_oracle_rows)(f1, "Eucl", list(range(c * per, min(1000, (c + 1) * per)))) for c in range(cores))
+        t_dist = time.perf_counter() - t0
+    out["c1_full"] = {"workload": "BASELINE config 1: 1 000 contigs x 2 kb (seed 1001), k=4 both strands, -d Eucl, whole job",
+                      "profiles_s": t_prof, "distances_s": t_dist, "pairs_per_s": 499500.0 / t_dist,
+                      "metric_calls": 1000 * 1000, "cores": cores}
+    return out
+
+
+def hbm_roofline(algo_bytes, kernel_ms, **extra):
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    d = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+    d.update(extra)
+    return d
 
 
 def main():
@@ -46,12 +105,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--contigs", type=int, default=50000, help="contigs at 1 GPU (BASELINE config 2)")
+    ap.add_argument("--contigs", type=int, default=0, help="override the number of contigs (default: 50 000 at 1 GPU = "
+                                                           "BASELINE config 2, 200 000 at N>1 = config 4)")
     ap.add_argument("--length", type=int, default=2000)
     ap.add_argument("--metric", default="JSD", choices=["Eucl", "JSD", "KT", "BC", "SC"])
     ap.add_argument("--pattern", default="1111")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 extras in config.other_configs")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 / KT extras in config.other_configs")
+    ap.add_argument("--no-complete-rows", action="store_true", help="N>1: skip timing the optional row-completing exchange")
     args = ap.parse_args()
 
     import torch
@@ -62,6 +123,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Environment switches of this harness and of the library are part of the record: PO_BENCH_* change what is run,
+    # any other PO_* would be a kernel-variant knob (none is read by the shipped library any more).
+    knobs = {k: v for k, v in sorted(os.environ.items()) if k.startswith("PO_")}
     # PO_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo collectives -- lets the N>1 code path be run on
     # a one-GPU box (numbers are meaningless then); the real run is one rank per GPU over RCCL.
     rehearsal = os.environ.get("PO_BENCH_REHEARSAL") == "1"
@@ -80,9 +144,14 @@ def main():
         dist = None
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local_rank)
+    cdev = "cpu" if rehearsal else dev            # where small collectives live (gloo in rehearsal)
 
-    n = args.contigs if world == 1 else int(round(args.contigs * math.sqrt(world) / (256 * world))) * 256 * world
-    seed = synthetic.SEEDS["C2"]
+    if args.contigs:
+        n, cfg_name, seed = args.contigs, "custom", synthetic.SEEDS["C2" if world == 1 else "C4"]
+    elif world == 1:
+        n, cfg_name, seed = 50000, "BASELINE config 2", synthetic.SEEDS["C2"]
+    else:
+        n, cfg_name, seed = 200000, "BASELINE config 4", synthetic.SEEDS["C4"]
     plan = RowBlockPlan(n, world)
     ctx = pa.Context(local_rank)
 
@@ -92,18 +161,27 @@ def main():
         synthetic.contig_bytes_range(n, args.length, seed, lo, hi)
     d_seq = torch.from_numpy(seq).to(dev)
     d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    ctx.count_profiles(d_seq, d_off, args.pattern, "both")          # untimed first call (allocations)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     my_counts, my_totals = ctx.count_profiles(d_seq, d_off, args.pattern, "both")
     torch.cuda.synchronize(dev)
     stage1_ms = (time.perf_counter() - t0) * 1e3
+    allgather_ms = None
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
     if rehearsal and dist is not None:
         counts, totals = plan.all_gather_profiles(my_counts.cpu(), my_totals.cpu(), dist)
         counts, totals = counts.to(dev), totals.to(dev)
     else:
         counts, totals = plan.all_gather_profiles(my_counts, my_totals, dist)
+    if dist is not None:
+        torch.cuda.synchronize(dev)
+        allgather_ms = (time.perf_counter() - t0) * 1e3
+    del d_seq
     dim = counts.shape[1]
-    rows = hi - lo
     slab, mirrors = plan.allocate(rank, dev, torch.float64)     # this rank's rows x all columns (+ mirror blocks)
     ctx.reserve(n, dim, args.metric)
 
@@ -125,76 +203,145 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    ranks_seen = 1
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        one = torch.ones(1, dtype=torch.int64, device=cdev)
+        dist.all_reduce(one)                                   # every rank that took part adds 1
+        ranks_seen = int(one.item())
+        assert ranks_seen == dist.get_world_size() == world
+
+    # dominant kernel: HIP-event time of the tile kernels on the launch stream (every rank, averaged)
+    kms = []
+    for _ in range(min(5, max(2, args.steps))):
+        st = step(want_stats=True)
+        kms.append(st["kernel_ms"])
+    kernel_ms = float(np.mean(kms))
+    rank_kernel_ms = [kernel_ms]
+    complete_rows_ms = None
+    if dist is not None:
+        g = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([kernel_ms], dtype=torch.float64, device=cdev))
+        rank_kernel_ms = [float(x.item()) for x in g]
+        if not args.no_complete_rows and not rehearsal and world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            plan.complete_rows(rank, slab, mirrors, dist)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t = torch.tensor([(time.perf_counter() - t0) * 1e3], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            complete_rows_ms = float(t.item())
 
     pairs = n * (n - 1) / 2.0
     ms_per_step = elapsed / args.steps * 1e3
-    result = None
     if rank == 0:
-        # dominant kernel: HIP-event time of the tile kernel on the launch stream, averaged
-        kms = []
-        for _ in range(min(5, max(2, args.steps))):
-            st = step(want_stats=True)
-            kms.append(st["kernel_ms"])
-        kernel_ms = float(np.mean(kms))
         main_kernel_id = st["kernel_id"]
         rc_folded = bool(st.get("rc_folded", False))
         rank_pairs = float(plan.pair_evaluations(rank))
         # compulsory HBM bytes per unordered pair = two mirrored float64 outputs + the
         # amortised one-time read of both profiles (uint32 counts)
         bytes_per_pair = 2 * 8 + 2 * dim * 4 / (n - 1)
-        algo_bytes = bytes_per_pair * rank_pairs
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
+        busy = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 traffic = json.load(fh).get("%s_n%d_d%d" % (args.metric, n, dim))
+        bpath = os.path.join(ROOT, "profiles", "pmc_busy.json")
+        if os.path.exists(bpath):
+            with open(bpath) as fh:
+                busy = json.load(fh)
+
+        def binding(kernel_key):
+            """the busiest on-chip resource of that kernel in the committed rocprofv3 --pmc passes"""
+            b = busy.get(kernel_key)
+            if not b:
+                return None
+            res = max((k for k in ("valu", "lds", "mfma") if b.get(k) is not None), key=lambda k: b[k])
+            return {"resource": res, "busy": b[res], "all": {k: b.get(k) for k in ("valu", "lds", "mfma")}, "source": busy.get("_source")}
+
+        main_key = {6: "jsd_lut_tile_kernel", 1: "valu_tile_kernel<JSD>", 4: "gram_i8_tile_kernel<1>", 3: "gram_tile_kernel<f64>",
+                    7: "bc_sad_tile_kernel", 2: "valu_tile_kernel<BC>", 8: "pairdot_tile_kernel<KT>", 9: "pairdot_tile_kernel<BC>"}.get(main_kernel_id)
+        roof = hbm_roofline(bytes_per_pair * rank_pairs, kernel_ms, traffic=traffic if world == 1 else None,
+                            kernel=KERNEL_NAMES.get(main_kernel_id, "tile kernel"), kernel_ms=kernel_ms, bytes_per_pair=bytes_per_pair,
+                            binding=binding(main_key),
+                            note="nominal roof per north_star; the JSD tile kernels are bound by LDS / vector-ALU issue, "
+                                 "not by HBM bytes (one table lookup or logarithm per word and pair for 16 B of output), see DESIGN.md section 3")
         general = None
-        if args.metric == "JSD":      # the same matrix through the general float64-log kernel only
-            gms = []
-            for _ in range(2):
-                gms.append(step(want_stats=True, table_path=False)["total_ms"])
-            general = {"ms": float(np.mean(gms)), "pairs_per_s": rank_pairs / (float(np.mean(gms)) * 1e-3)}
-        kernel_names = {1: "valu_tile_kernel<JSD>", 2: "valu_tile_kernel<BC>", 3: "gram_tile_kernel (f64 MFMA)",
-                        5: "kt_tile_kernel", 6: "jsd_lut_tile_kernel (equal-total record blocks) + valu_tile_kernel<JSD> (rest)"}
+        if args.metric == "JSD" and world == 1:      # the same matrix through the general float64-log kernel only
+            gms = [step(want_stats=True, table_path=False) for _ in range(2)]
+            g_ms = float(np.mean([x["total_ms"] for x in gms]))
+            g_kms = float(np.mean([x["kernel_ms"] for x in gms]))
+            general = {"ms": g_ms, "kernel_ms": g_kms, "pairs_per_s": rank_pairs / (g_ms * 1e-3),
+                       "roofline": hbm_roofline(bytes_per_pair * rank_pairs, g_kms, binding=binding("valu_tile_kernel<JSD>")),
+                       "what": "valu_tile_kernel<JSD>: the kernel a ragged real assembly gets (totals differ inside every "
+                               "128-record block, or counts above 127)"}
+        workload = ("%s: %d synthetic contigs x %d bp (seed %d), pattern %s both strands, -d %s, float64 matrix resident in HBM"
+                    % (cfg_name, n, args.length, seed, args.pattern, args.metric))
         result = {
             "metric": "contig-pairs/sec", "value": pairs / (elapsed / args.steps), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d synthetic contigs x %d bp (seed %d), pattern %s both strands, -d %s, "
-                                   "float64 matrix resident in HBM" % (n, args.length, seed, args.pattern, args.metric),
-                       "contigs": n, "dim": dim, "pairs": pairs, "sharding": plan.describe(),
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": workload, "contigs": n, "dim": dim, "pairs": pairs, "sharding": plan.describe(),
                        "stage1_profile_ms": stage1_ms, "matrix_wall_ms": ms_per_step,
                        "rc_folded": rc_folded,      # strand-symmetric profiles summed over one word per {w, rc(w)} orbit
-                       "jsd_general_kernel_only": general},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_names.get(main_kernel_id, "tile kernel"),
-                         "kernel_ms": kernel_ms, "bytes_per_pair": bytes_per_pair,
-                         "note": "nominal roof per north_star; the tile kernels are bound by vector-ALU / LDS issue, "
-                                 "not by HBM bytes, see DESIGN.md section 3"},
+                       "equal_total_table_path": main_kernel_id == 6,
+                       "table_path_needs": "every 128-record block to share one word total and counts <= 127 (fixed-length "
+                                           "contigs, windows, reads); otherwise jsd_general_kernel_only is the rate",
+                       "jsd_general_kernel_only": general,
+                       "env_knobs": knobs},
+            "roofline": roof,
         }
-        if world == 1 and args.metric == "JSD" and args.contigs == 50000 and not args.no_other_configs:
-            # the other single-GPU BASELINE configurations, timed the same way (not part of `value`): C3 = the same
-            # assembly with -d Eucl, C5 = pattern 11011011 (D = 4096) with -d BC
+        if world > 1 or dist is not None:
+            result["config"]["multi_gpu"] = {
+                "ranks_seen": ranks_seen, "backend": "gloo (rehearsal on one GPU)" if rehearsal else "nccl (RCCL)",
+                "allgather_ms": allgather_ms, "allgather_bytes": int(counts.numel() * 4 + totals.numel() * 8),
+                "complete_rows_ms": complete_rows_ms,
+                "kernel_ms_min": min(rank_kernel_ms), "kernel_ms_max": max(rank_kernel_ms), "kernel_ms_per_rank": rank_kernel_ms,
+                "pairs_rank0": rank_pairs,
+                "note": "all-gather = the single exchange of the path, outside the timed region like stage 1; "
+                        "complete_rows = optional second exchange delivering mirror blocks to row owners, not part of `value`"}
+        if world == 1 and args.metric == "JSD" and n == 50000 and not args.no_other_configs:
+            # the other single-GPU BASELINE configurations, timed the same way (not part of `value`)
             others = {}
             try:
-                def timed(c, t, metric):
+                def timed(c, t, metric, **kw):
                     best = None
                     for _ in range(3):
-                        _, st = ctx.pairwise(c, t, metric, out=slab, want_stats=True)
-                        if best is None or st["total_ms"] < best["total_ms"]:
-                            best = st
+                        _, s2 = ctx.pairwise(c, t, metric, out=slab, want_stats=True, **kw)
+                        if best is None or s2["total_ms"] < best["total_ms"]:
+                            best = s2
+                    d_ = c.shape[1]
+                    bpp = 16 + 2 * d_ * 4 / (n - 1)
                     return {"ms": best["total_ms"], "kernel_ms": best["kernel_ms"], "pairs_per_s": pairs / (best["total_ms"] * 1e-3),
-                            "kernel_id": best["kernel_id"], "rc_folded": best["rc_folded"]}
-                others["C3 Eucl k=4"] = timed(counts, totals, "Eucl")
+                            "kernel_id": best["kernel_id"], "kernel": KERNEL_NAMES.get(best["kernel_id"]), "rc_folded": best["rc_folded"],
+                            "roofline": hbm_roofline(bpp * pairs, best["kernel_ms"])}
+                e = timed(counts, totals, "Eucl")
+                e["roofline"]["bound"] = "hbm-store"
+                e["roofline"]["binding"] = binding("gram_i8_tile_kernel<1>")
+                e["roofline"]["note"] = ("exact int8-MFMA Gram: matrix-core time ~0.1 ms, the kernel is bound by writing 16 B per pair; "
+                                         "bare store pattern of this tiling measures 6.1 TB/s (profiles/r01_store_bandwidth.txt)")
+                others["C3 Eucl k=4 (default path: exact int8 MFMA)"] = e
+                f = timed(counts, totals, "Eucl", table_path=False)
+                tf = 2.0 * dim * pairs / (f["kernel_ms"] * 1e-3) / 1e12
+                f["roofline"] = {"bound": "mfma-f64", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TF,
+                                 "flops_per_pair": 2 * dim, "binding": binding("gram_tile_kernel<f64>"),
+                                 "note": "forced float64 path (v_mfma_f64_16x16x4_f64), the path north_star's MFMA target is quoted on"}
+                others["C3 Eucl k=4 (float64 MFMA path, table_path=False)"] = f
+                k = timed(counts, totals, "KT")
+                k["roofline"]["binding"] = binding("pairdot_tile_kernel<KT>")
+                others["C2-size KT k=4"] = k
                 seq5, off5 = synthetic.contig_bytes(n, args.length, seed=synthetic.SEEDS["C5"])
                 c5, t5 = ctx.count_profiles(torch.from_numpy(seq5).to(dev), torch.from_numpy(off5.astype(np.int64)).to(dev),
                                             "11011011", "both")
-                others["C5 BC pattern 11011011"] = timed(c5, t5, "BC")
+                b5 = timed(c5, t5, "BC")
+                b5["roofline"]["binding"] = binding("pairdot_tile_kernel<BC>" if b5["kernel_id"] == 9 else "bc_sad_tile_kernel")
+                others["C5 BC pattern 11011011"] = b5
                 del c5, t5
             except Exception as exc:             # never let the extras break the headline line
                 others["error"] = repr(exc)
@@ -202,7 +349,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import phyloligo_oracle as po
             freq = po.counts_to_frequencies(counts.cpu().numpy().astype(np.int64), totals.cpu().numpy())
-            result["cpu_baseline"] = cpu_baseline_jsd(freq, args.metric, budget_rows=128)
+            result["cpu_baseline"] = cpu_baseline(freq, args.metric)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

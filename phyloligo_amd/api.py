@@ -89,6 +89,9 @@ class Context:
             n = offsets.numel() - 1
             assert seq.dtype == torch.uint8 and seq.is_cuda and seq.is_contiguous()
             assert offsets.dtype == torch.int64 and offsets.is_cuda and offsets.is_contiguous()
+            if seq.device.index != self.device or offsets.device != seq.device:
+                raise _lib.PhyloligoError(_lib.PO_EINVAL, "tensors are on %s / %s, this context drives cuda:%d"
+                                          % (seq.device, offsets.device, self.device))
             counts = torch.empty((n, dim), dtype=torch.int32, device=seq.device)
             totals = torch.empty((n,), dtype=torch.int64, device=seq.device)
             self._use_torch_stream()
@@ -221,8 +224,15 @@ class Context:
         sp = ctypes.byref(stats) if want_stats else None
         if _is_torch(src):
             import torch
+            want = torch.float32 if f32 else torch.float64
+            if src.device.type != "cuda" or src.device.index != self.device:
+                raise _lib.PhyloligoError(_lib.PO_EINVAL, "input tensor is on %s, this context drives cuda:%d" % (src.device, self.device))
             if out is None:
-                out = torch.empty((rows, n), dtype=torch.float32 if f32 else torch.float64, device=src.device)
+                out = torch.empty((rows, n), dtype=want, device=src.device)
+            elif not (_is_torch(out) and out.dtype == want and out.device == src.device and out.dim() == 2 and
+                      out.shape[0] >= rows and out.shape[1] >= n and (out.stride(1) == 1 or out.shape[1] <= 1)):
+                raise _lib.PhyloligoError(_lib.PO_EINVAL, "out must be a %s tensor [>=%d, >=%d] with unit inner stride on %s"
+                                          % (want, rows, n, src.device))
             ld = out.stride(0) if rows > 1 else max(n, out.stride(0) if out.dim() == 2 else n)
             self._use_torch_stream()
             if freq is not None:
@@ -235,8 +245,15 @@ class Context:
                 check(self._lib.po_pairwise_dev(self._h, counts.data_ptr(), totals.data_ptr(), n, dim, METRICS[metric],
                                                 row_begin, row_end, code, out.data_ptr(), ld, flags, sp))
         else:
+            want = np.float32 if f32 else np.float64
             if out is None:
-                out = np.zeros((rows, n), dtype=np.float32 if f32 else np.float64)
+                out = np.zeros((rows, n), dtype=want)
+            elif not (isinstance(out, np.ndarray) and out.dtype == want and out.ndim == 2 and out.flags.writeable and
+                      out.shape[0] >= rows and out.shape[1] >= n and
+                      (out.strides[1] == out.itemsize or out.shape[1] <= 1) and out.strides[0] % out.itemsize == 0 and
+                      (out.strides[0] >= n * out.itemsize or rows <= 1)):
+                raise _lib.PhyloligoError(_lib.PO_EINVAL, "out must be a writeable %s array [>=%d, >=%d] with unit inner stride"
+                                          % (np.dtype(want).name, rows, n))
             ld = out.strides[0] // out.itemsize if rows > 0 and n > 0 else n
             if freq is not None:
                 freq = np.ascontiguousarray(freq, dtype=np.float64)
@@ -303,6 +320,8 @@ def fasta_index(data):
 def write_mat_text(path, m, append=False):
     """numpy.savetxt(path, m, delimiter="\\t") byte for byte (bin/phyloligo.py:1061,1066)."""
     lib = _lib.load()
+    if m is None:
+        raise _lib.PhyloligoError(_lib.PO_EINVAL, "write_mat_text: no matrix to write (got None)")
     m = np.ascontiguousarray(m, dtype=np.float64)
     if m.ndim == 1:
         m = m.reshape(-1, 1)      # savetxt writes a 1-D array one value per line

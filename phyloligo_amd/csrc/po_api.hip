@@ -133,6 +133,24 @@ int po_buf_reserve(po_ctx* ctx, po_buf* b, size_t bytes) {
     return PO_OK;
 }
 
+int po_func_shmem(po_ctx* ctx, const void* func, size_t bytes) {
+    for (int i = 0; i < ctx->n_shmem_set; ++i)
+        if (ctx->shmem_set[i].func == func) {
+            if (ctx->shmem_set[i].bytes >= bytes) return PO_OK;
+            PO_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            ctx->shmem_set[i].bytes = bytes;
+            return PO_OK;
+        }
+    PO_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const int cap = (int)(sizeof(ctx->shmem_set) / sizeof(ctx->shmem_set[0]));
+    if (ctx->n_shmem_set < cap) {          // a full table only costs the repeated attribute call
+        ctx->shmem_set[ctx->n_shmem_set].func = func;
+        ctx->shmem_set[ctx->n_shmem_set].bytes = bytes;
+        ++ctx->n_shmem_set;
+    }
+    return PO_OK;
+}
+
 // ---- pattern -------------------------------------------------------------------------------
 int po_pattern_compile(const char* pattern, po_pattern* out) {
     PO_REQUIRE(pattern != nullptr && out != nullptr, "pattern is NULL");
@@ -595,8 +613,6 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         a.ld_mirror = k.triangular ? k.ld_out : k.ld_mirror;
         a.out_f32 = (out_dtype == PO_F32);
         a.dbl_at = dbl_at;
-        static const bool dbg_no_mirror = getenv("PO_DEBUG_NO_MIRROR") != nullptr;   // timing experiments only
-        if (dbg_no_mirror) a.mirror = nullptr;
         switch (metric) {
             case PO_JSD:
                 if (cls) {

@@ -407,7 +407,7 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     const bool narrow = 2 * pat.window <= 32;
     const int mode = (strand == PO_STRAND_PLUS || P.sym) ? 0 : (strand == PO_STRAND_MINUS ? 1 : 2);
     auto launch = [&](auto k) -> int {
-        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        PO_SHMEM(ctx, k, shmem);
         hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), shmem, ctx->stream, d_seq, d_begins, d_ends, chunk_start, P, wpb, d_counts, tot);
         return PO_OK;
     };

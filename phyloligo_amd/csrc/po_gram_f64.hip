@@ -208,8 +208,8 @@ int launch_gram(po_ctx* ctx, const po_tile_args& a, const double* norms, const u
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
     const size_t shmem = 2 * kStageDoubles * sizeof(double);
-    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tile_kernel<METRIC, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_tile_kernel<METRIC, double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    PO_SHMEM(ctx, (gram_tile_kernel<METRIC, float>), shmem);
+    PO_SHMEM(ctx, (gram_tile_kernel<METRIC, double>), shmem);
     if (a.out_f32)
         hipLaunchKernelGGL((gram_tile_kernel<METRIC, float>), dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, norms, i8flag, i8_upto);
     else

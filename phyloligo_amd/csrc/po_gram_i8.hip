@@ -260,11 +260,11 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
     const size_t shmem = (staging > (size_t)kMirrorBytes ? staging : (size_t)kMirrorBytes) + kTermBytes;
     if (a.out_f32) {
         auto k = gram_i8_tile_kernel<P, METRIC, float>;
-        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        PO_SHMEM(ctx, k, shmem);
         hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto);
     } else {
         auto k = gram_i8_tile_kernel<P, METRIC, double>;
-        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        PO_SHMEM(ctx, k, shmem);
         hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto);
     }
     PO_CHECK_LAUNCH("gram_i8_tile_kernel");

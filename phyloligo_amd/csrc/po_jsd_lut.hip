@@ -243,19 +243,14 @@ int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, cons
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
     const size_t shmem = kLutBytes + 2 * kStageWords * sizeof(uint32_t);
-    static const int rpt = getenv("PO_LUT_RPT") ? atoi(getenv("PO_LUT_RPT")) : 4;
-    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jsd_lut_tile_kernel<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jsd_lut_tile_kernel<float, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jsd_lut_tile_kernel<double, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jsd_lut_tile_kernel<double, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    if (a.out_f32 && rpt == 4)
+    // 4 rows per lane (512 lanes per tile); the 8-row / 256-lane variant measured slower (round 1)
+    if (a.out_f32) {
+        PO_SHMEM(ctx, (jsd_lut_tile_kernel<float, 4>), shmem);
         hipLaunchKernelGGL((jsd_lut_tile_kernel<float, 4>), dim3((uint32_t)nblocks), dim3(512), shmem, ctx->stream, a, ct, lut, cls);
-    else if (a.out_f32)
-        hipLaunchKernelGGL((jsd_lut_tile_kernel<float, 8>), dim3((uint32_t)nblocks), dim3(256), shmem, ctx->stream, a, ct, lut, cls);
-    else if (rpt == 4)
+    } else {
+        PO_SHMEM(ctx, (jsd_lut_tile_kernel<double, 4>), shmem);
         hipLaunchKernelGGL((jsd_lut_tile_kernel<double, 4>), dim3((uint32_t)nblocks), dim3(512), shmem, ctx->stream, a, ct, lut, cls);
-    else
-        hipLaunchKernelGGL((jsd_lut_tile_kernel<double, 8>), dim3((uint32_t)nblocks), dim3(256), shmem, ctx->stream, a, ct, lut, cls);
+    }
     PO_CHECK_LAUNCH("jsd_lut_tile_kernel");
     return PO_OK;
 }

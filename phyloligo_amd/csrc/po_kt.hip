@@ -199,7 +199,7 @@ int po_launch_ranks(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq,
     if (d_counts) {
         auto k = row_order_kernel<uint32_t, true>;
         const size_t shmem = 2 * kValueBins * sizeof(uint32_t);
-        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        PO_SHMEM(ctx, k, shmem);
         hipLaunchKernelGGL(k, dim3((uint32_t)n), dim3(kThreads), shmem, ctx->stream, d_counts, n, dim, npad, d_rt, d_lessrank,
                            d_r2, d_rowstat);
     } else {

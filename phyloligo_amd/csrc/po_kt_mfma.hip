@@ -303,9 +303,8 @@ int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, 
     // Rounds of 4 K-steps and 8 expanding waves are the default.  Both alternatives were built and measured at
     // N = 50 000, folded k = 4 (45.2 ms): 6 K-steps per round (fewer barriers, needs the larger sign tiles to fit LDS)
     // 46.2 ms, 12 expanding waves 48.5 ms - neither the barrier count nor the number of expanding lanes paces
-    // the kernel.  They stay selectable for experiments: PO_KT_KSTEPS=6, PO_KT_PWAVES=12.
-    static const bool want12 = getenv("PO_KT_PWAVES") && atoi(getenv("PO_KT_PWAVES")) == 12;
-    static const bool want6 = want12 || (getenv("PO_KT_KSTEPS") && atoi(getenv("PO_KT_KSTEPS")) == 6);
+    // the kernel.  The variants stay in the source, not selectable at run time.
+    const bool want12 = false, want6 = false;
     const bool fits6 = 256 * (size_t)(row_bytes + 16) + 2 * 256 * (size_t)kt_sig_stride(6) + 4096 <= 160 * 1024;
     const int ksv = (fits6 && want6) ? 6 : 4;
     const int pwaves = (want12 && ksv == 6) ? 12 : 8;
@@ -364,7 +363,7 @@ int po_launch_kt_mfma_tiles(po_ctx* ctx, const po_tile_args& a_in, const void* w
     const size_t shmem = ((256 * (plan.row_bytes + 16) + 15) & ~(size_t)15) + 2 * 256 * (size_t)kt_sig_stride((int)plan.ksteps) +
                          ((plan.n_items * 2 + 15) & ~(size_t)15);
     auto launch = [&](auto k) -> int {
-        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        PO_SHMEM(ctx, k, shmem);
         hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, rank8, d_items, plan.n_items,
                            plan.row_bytes, dim_full, plan.dbl1, plan.dbl2);
         return PO_OK;

@@ -319,12 +319,12 @@ int po_launch_kt_panel_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws,
     const size_t shmem = 2 * 256 * kRankStride + 2 * 256 * kSigStride + ((plan.n_diag_items * 2 + 15) & ~(size_t)15);
     if (a.out_f32) {
         auto k = kt_panel_tile_kernel<float>;
-        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        PO_SHMEM(ctx, k, shmem);
         hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, rank16, plan.row_words, plan.words,
                            a.dim, plan.self_panels, plan.folded, d_items, plan.n_diag_items);
     } else {
         auto k = kt_panel_tile_kernel<double>;
-        PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        PO_SHMEM(ctx, k, shmem);
         hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, rank16, plan.row_words, plan.words,
                            a.dim, plan.self_panels, plan.folded, d_items, plan.n_diag_items);
     }

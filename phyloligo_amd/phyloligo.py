@@ -92,6 +92,14 @@ def compute_distances(mthdrun, large, frequencies, freq_name, out_file, dist, th
     counts = getattr(frequencies, "counts", None)
     totals = getattr(frequencies, "totals", None)
     n = frequencies.shape[0]
+    if mthdrun == "scoop":                   # compute_distances_scoop (:313-362) has no --large variants
+        large = "None"
+    # The reference computes from the array it is handed.  The integer profiles riding on a ProfileMatrix are only
+    # a shortcut while they still ARE that array: in-place edits (frequencies *= w, frequencies[mask] = 0, ...)
+    # keep the attributes, so check count/total == array bit for bit and otherwise go by the array's values.
+    if counts is not None and (counts.shape != frequencies.shape or
+                               not np.array_equal(ctx.frequencies(counts, totals), np.asarray(frequencies))):
+        counts = totals = None
 
     def rows(lo, hi, dtype, symmetric):
         if counts is not None:
@@ -173,9 +181,10 @@ def main(argv=None):
     if params.out_freq_file:
         print("Writing frequency matrix")
         api.write_mat_text(params.out_freq_file, np.asarray(frequencies))
-    if not (params.mthdrun in ("joblib", "hip") and params.large != "None"):
+    if not (params.mthdrun in ("joblib", "hip") and params.large != "None"):      # :1064
         print("Writing distance matrix")
-        api.write_mat_text(params.out_file, res)
+        if res is not None:                  # None: unknown --method, nothing was computed (:552 only prints)
+            api.write_mat_text(params.out_file, res)
     return 0
 
 

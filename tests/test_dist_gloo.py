@@ -47,7 +47,7 @@ def test_all_gather_profiles_world2(n):
     assert spans[0][0] == 0 and spans[-1][1] == n and spans[0][1] == spans[1][0]
 
 
-def _exchange_worker(rank, world, port, n, ret):
+def _exchange_worker(rank, world, port, n, chunk_bytes, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -62,17 +62,18 @@ def _exchange_worker(rank, world, port, n, ret):
         for (r0, r1), (c0, c1), kind, peer in plan.work(rank):   # stand-in for plan.compute()
             slab[r0 - lo:r1 - lo, c0:c1] = full[r0:r1, c0:c1]
             mirrors.append(None if kind == "diag" else full[r0:r1, c0:c1].T.contiguous())
-        plan.complete_rows(rank, slab, mirrors, dist)
+        plan.complete_rows(rank, slab, mirrors, dist, chunk_bytes=chunk_bytes)
         ret[rank] = bool(torch.equal(slab, full[lo:hi]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 100), (3, 100), (4, 131)])
-def test_complete_rows_exchange(world, n):
+@pytest.mark.parametrize("world,n,chunk_bytes", [(2, 100, 256 << 20), (3, 100, 256 << 20), (4, 131, 256 << 20),
+                                                 (2, 100, 1024), (4, 131, 700)])     # small chunks: several steps per message
+def test_complete_rows_exchange(world, n, chunk_bytes):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_exchange_worker, args=(world, _free_port(), n, ret), nprocs=world, join=True)
+    mp.spawn(_exchange_worker, args=(world, _free_port(), n, chunk_bytes, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world))
 
 
