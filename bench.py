@@ -50,32 +50,66 @@ def _oracle_profiles(seqs):
     return po.compute_frequencies(seqs, "1111", "both")
 
 
-def cpu_baseline(freq, metric, budget_s=12.0):
+def usable_cores():
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup CPU quota when there is one
+    (a GPU box shows all 256 hardware threads of the host to os.cpu_count() but gives a one-GPU job a share of them)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = fh.read().split()
+            if q != "max":
+                quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, p = float(fq.read()), float(fp.read())
+                if q > 0:
+                    quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
+def _timed_rows(freq, metric, row0, budget_s):
+    """one worker: rows row0, row0 + 1, ... of the oracle's per-pair loop until budget_s is used up"""
+    from oracle import phyloligo_oracle as po
+    t0 = time.perf_counter()
+    rows = 0
+    while True:
+        po.pairwise_rows(freq, metric, [(row0 + rows) % freq.shape[0]])
+        rows += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or rows >= 64:
+            return rows, dt
+
+
+def cpu_baseline(freq, metric, budget_s=10.0, cores=None):
     """The oracle's per-pair Python path (= the reference's joblib path: one metric call per pair under
-    sklearn.pairwise_distances, phyloligo.py:364-392) on os.cpu_count() processes.
-    (1) a bounded slab of rows x all columns of THIS workload; (2) BASELINE config 1 in full (1 000 contigs, Eucl:
-    Counter-style profiles + 10^6 metric calls), as SURVEY 8d asks."""
+    sklearn.pairwise_distances, phyloligo.py:364-392) on every CPU this job may use.
+    (1) a time-bounded slab of rows x all columns of THIS workload (each worker evaluates whole rows until budget_s is
+    used up); (2) BASELINE config 1 in full (1 000 contigs, Eucl: profiles + 10^6 metric calls), as SURVEY 8d asks."""
     import joblib
     from oracle import phyloligo_oracle as po
-    cores = os.cpu_count() or 1
+    cores = cores or usable_cores()
     n = freq.shape[0]
-    # probe the per-call cost on one core, then size the slab to ~budget_s of wall time on all cores
-    t0 = time.perf_counter()
-    po.pairwise_rows(freq[:2000], metric, [0])
-    per_call = (time.perf_counter() - t0) / min(n, 2000)
-    rows_per = max(1, int(budget_s / max(per_call * n, 1e-9)))
-    rows_per = min(rows_per, 64, max(1, n // cores))
-    slabs = [list(range(c * rows_per, (c + 1) * rows_per)) for c in range(cores) if (c + 1) * rows_per <= n]
     with joblib.Parallel(n_jobs=cores) as par:
         par(joblib.delayed(_oracle_rows)(freq[:8], metric, [0]) for _ in range(cores))          # start the workers
         t0 = time.perf_counter()
-        par(joblib.delayed(_oracle_rows)(freq, metric, rows) for rows in slabs)
+        done = par(joblib.delayed(_timed_rows)(freq, metric, c * 64, budget_s) for c in range(cores))
         dt = time.perf_counter() - t0
-        evaluated = len(slabs) * rows_per * n
+        rows = sum(r for r, _ in done)
+        evaluated = rows * n
         out = {"value": evaluated / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+               "host_cpus_visible": os.cpu_count(),
                "sample": "%d rows x %d columns = %d metric calls of oracle.%s (per-pair numpy path of phylodist.py under "
                          "sklearn.pairwise_distances semantics) in %.1f s over %d processes"
-                         % (len(slabs) * rows_per, n, evaluated, metric, dt, cores)}
+                         % (rows, n, evaluated, metric, dt, cores)}
         # ---- BASELINE config 1, whole: 1 000 contigs x 2 kb, k=4 both strands, -d Eucl ----
         seqs = po.synthetic_contigs(1000, 2000, seed=1001)
         per = -(-len(seqs) // cores)
@@ -85,7 +119,8 @@ def cpu_baseline(freq, metric, budget_s=12.0):
         t_prof = time.perf_counter() - t0
         per = -(-1000 // cores)
         t0 = time.perf_counter()
-        par(joblib.delayed(_oracle_rows)(f1, "Eucl", list(range(c * per, min(1000, (c + 1) * per)))) for c in range(cores))
+        par(joblib.delayed(_oracle_rows)(f1, "Eucl", list(range(c * per, min(1000, (c + 1) * per)))) for c in range(cores)
+            if c * per < 1000)
         t_dist = time.perf_counter() - t0
     out["c1_full"] = {"workload": "BASELINE config 1: 1 000 contigs x 2 kb (seed 1001), k=4 both strands, -d Eucl, whole job",
                       "profiles_s": t_prof, "distances_s": t_dist, "pairs_per_s": 499500.0 / t_dist,
@@ -93,8 +128,8 @@ def cpu_baseline(freq, metric, budget_s=12.0):
     return out
 
 
-def hbm_roofline(algo_bytes, kernel_ms, **extra):
-    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+def hbm_roofline(algo_bytes, ms, **extra):
+    achieved = algo_bytes / (ms * 1e-3) / 1e9
     d = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
     d.update(extra)
     return d

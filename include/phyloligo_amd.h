@@ -81,6 +81,14 @@ typedef enum po_dtype { PO_F64 = 0, PO_F32 = 1 } po_dtype;
                                  the work.  The check reads one flag word back, i.e. it synchronises the
                                  stream once per call; this flag avoids that.                             */
 
+#define PO_FLAG_PAIRDOT_I8 8u /* KT (dim <= 256) and BC on thermometer planes: keep the materialised {-1,0,1} operand as
+                                int8 and use v_mfma_i32_32x32x32_i8 instead of the default FP4 (E2M1) operand with
+                                v_mfma_scale_f32_32x32x64_f8f6f4.  Both are exact; results are bit-identical.   */
+
+#define PO_FLAG_NO_PAIRDOT 16u /* KT / BC: do not materialise pair-sign / thermometer operands for the matrix cores; BC then
+                                 takes the packed-byte SAD kernel (equal-total blocks) and the general kernel, KT at
+                                 dim <= 256 the O(D^2) vector kernel.  For cross-checks and timing comparisons.      */
+
 /* Filled by po_pairwise* when non-NULL.  Times are HIP-event times on the context's stream;
  * asking for them makes the call synchronise. */
 typedef struct po_stats {
@@ -98,7 +106,8 @@ typedef struct po_stats {
 #define PO_KERNEL_MFMA_F64_GRAM 3u
 #define PO_KERNEL_MFMA_I8_GRAM 4u  /* exact int8 kernels (counts <= 16383; Spearman ranks, dim <= 8191), else the float64 one */
 #define PO_KERNEL_VALU_KT 5u
-#define PO_KERNEL_MFMA_I8_KT 8u /* Kendall tau as an int8-MFMA Gram over pair-sign vectors (dim <= 256) */
+#define PO_KERNEL_MFMA_I8_KT 8u /* Kendall tau as an exact matrix-core Gram over pair-sign vectors (FP4 / int8 operands) */
+#define PO_KERNEL_MFMA_BC 9u    /* Bray-Curtis as s_a + s_b - 2 <thermometer(a), thermometer(b)> on the matrix cores   */
 #define PO_KERNEL_SAD_BC 7u    /* packed-byte SAD kernel (equal-total blocks) + general kernel for the rest */
 #define PO_KERNEL_LUT_JSD 6u   /* integer-sum table kernel + general kernel for the remaining tiles */
 

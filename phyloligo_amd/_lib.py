@@ -20,6 +20,8 @@ PO_F64, PO_F32 = 0, 1
 PO_FLAG_NO_SYMMETRY = 1
 PO_FLAG_NO_TABLE_PATH = 2
 PO_FLAG_NO_RC_FOLD = 4
+PO_FLAG_PAIRDOT_I8 = 8
+PO_FLAG_NO_PAIRDOT = 16
 
 
 class PoStats(ctypes.Structure):

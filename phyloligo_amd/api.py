@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import (METRICS, STRANDS, PO_F32, PO_F64, PO_FLAG_NO_SYMMETRY, PO_FLAG_NO_TABLE_PATH, PO_FLAG_NO_RC_FOLD, PoBlock, PoStats,
+from ._lib import (METRICS, STRANDS, PO_F32, PO_F64, PO_FLAG_NO_SYMMETRY, PO_FLAG_NO_TABLE_PATH, PO_FLAG_NO_RC_FOLD, PO_FLAG_PAIRDOT_I8, PO_FLAG_NO_PAIRDOT, PoBlock, PoStats,
                    check)
 
 
@@ -159,12 +159,15 @@ class Context:
         check(self._lib.po_pairwise_reserve(self._h, n, dim, METRICS[metric]))
 
     def pairwise(self, counts, totals, metric="Eucl", row_begin=0, row_end=None, dtype="float64", symmetric=True,
-                 out=None, want_stats=False, table_path=True, rc_fold=True):
+                 out=None, want_stats=False, table_path=True, rc_fold=True, pairdot_i8=False, pairdot=True):
         """Rows [row_begin,row_end) x all columns of the distance matrix from integer profiles.
         table_path=False forces the general JSD kernel even for record blocks with equal totals;
-        rc_fold=False keeps every word even when the profiles are reverse-complement symmetric."""
+        rc_fold=False keeps every word even when the profiles are reverse-complement symmetric;
+        pairdot_i8=True keeps the materialised KT / BC operand as int8 instead of FP4 (same results);
+        pairdot=False leaves KT / BC to the vector-ALU kernels (SAD / O(D^2) Kendall)."""
         return self._pairwise(counts, totals, None, metric, row_begin, row_end, dtype, symmetric, out, want_stats,
-                              (0 if table_path else PO_FLAG_NO_TABLE_PATH) | (0 if rc_fold else PO_FLAG_NO_RC_FOLD))
+                              (0 if table_path else PO_FLAG_NO_TABLE_PATH) | (0 if rc_fold else PO_FLAG_NO_RC_FOLD) |
+                              (PO_FLAG_PAIRDOT_I8 if pairdot_i8 else 0) | (0 if pairdot else PO_FLAG_NO_PAIRDOT))
 
     def pairwise_freq(self, freq, metric="Eucl", row_begin=0, row_end=None, dtype="float64", symmetric=True,
                       out=None, want_stats=False, rc_fold=True, table_path=True):
@@ -175,7 +178,7 @@ class Context:
                               (0 if rc_fold else PO_FLAG_NO_RC_FOLD) | (0 if table_path else PO_FLAG_NO_TABLE_PATH))
 
     def pairwise_blocks(self, counts, totals, metric, blocks, dtype="float64", want_stats=False, table_path=True,
-                        rc_fold=True):
+                        rc_fold=True, pairdot_i8=False):
         """Several rectangular blocks of one matrix in one call (device tensors only).  `blocks` is a
         list of dicts: rows=(lo,hi), cols=(lo,hi), out=<2-D tensor [rows, cols]>, optional
         mirror=<2-D tensor [cols, rows]>, optional triangular=True (rows == cols)."""
@@ -201,7 +204,8 @@ class Context:
         check(self._lib.po_pairwise_blocks_dev(self._h, counts.data_ptr(), totals.data_ptr(), n, dim, METRICS[metric],
                                                PO_F32 if f32 else PO_F64, arr, len(blocks),
                                                (0 if table_path else PO_FLAG_NO_TABLE_PATH) |
-                                               (0 if rc_fold else PO_FLAG_NO_RC_FOLD),
+                                               (0 if rc_fold else PO_FLAG_NO_RC_FOLD) |
+                                               (PO_FLAG_PAIRDOT_I8 if pairdot_i8 else 0),
                                                ctypes.byref(stats) if want_stats else None))
         if want_stats:
             return {"prep_ms": stats.prep_ms, "kernel_ms": stats.kernel_ms, "total_ms": stats.total_ms,

@@ -7,6 +7,7 @@
 
 #include <stdarg.h>
 #include <stdlib.h>
+#include <sys/mman.h>
 
 #include <new>
 
@@ -90,6 +91,9 @@ extern "C" void po_ctx_destroy(po_ctx* ctx) {
     buf_free(&ctx->ws_fold);
     buf_free(&ctx->ws_fold_src);
     buf_free(&ctx->ws_recover);
+    buf_free(&ctx->ws_pairdot);
+    buf_free(&ctx->ws_pq);
+    buf_free(&ctx->ws_thermo);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     for (int i = 0; i < 2; ++i)
         if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
@@ -408,8 +412,8 @@ static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
     } else {
         rc = po_buf_reserve(ctx, &ctx->ws_aux, n * (uint64_t)dim * sizeof(uint32_t));
         if (rc) return rc;
-        if (po_kt_mfma_supported(dim)) {      // uint8 ranks + word-pair items of the MFMA kernel
-            rc = po_buf_reserve(ctx, &ctx->ws_freq, po_kt_mfma_workspace(n, dim));
+        if (po_kt_pairdot_supported(dim)) {   // uint8 ranks + the materialised pair-sign operand
+            rc = po_buf_reserve(ctx, &ctx->ws_freq, po_kt_pairdot_rank_bytes(n, dim));
             if (rc) return rc;
         } else if (po_kt_panel_supported(dim)) {   // uint16 ranks of the panel kernel
             rc = po_buf_reserve(ctx, &ctx->ws_freq, po_kt_panel_workspace(n, dim));
@@ -550,19 +554,21 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         rc = po_launch_ranks(ctx, d_freq ? nullptr : d_counts, d_freq, n, dim, npad, nullptr, lessrank, nullptr, rowstat);
     }
     if (rc) return rc;
-    po_kt_mfma_plan kt_plan;
+    po_pairdot_plan kt_plan, bc_plan;
+    bool bc_thermo = false;
+    double bc_inv_n = 0.0;
+    memset(&bc_plan, 0, sizeof(bc_plan));
     po_kt_panel_plan kt_pplan;
     memset(&kt_plan, 0, sizeof(kt_plan));
     memset(&kt_pplan, 0, sizeof(kt_pplan));
-    const bool kt_mfma = metric == PO_KT && po_kt_mfma_supported(dim) && !(flags & PO_FLAG_NO_TABLE_PATH);
+    const bool kt_mfma = metric == PO_KT && po_kt_pairdot_supported(dim) && !(flags & (PO_FLAG_NO_TABLE_PATH | PO_FLAG_NO_PAIRDOT));
     const bool kt_panel = metric == PO_KT && !kt_mfma && po_kt_panel_supported(dim) && !(flags & PO_FLAG_NO_TABLE_PATH);
     if (kt_mfma || kt_panel) {
         // strand-symmetric records: Kendall's S over one word per reverse-complement orbit, weighted (po_fold.hip)
         const uint32_t selfs = po_fold_selfs(dim);
         const uint32_t* fold_src = nullptr;
         uint32_t fold_len = 0;
-        const bool can_fold = selfs != 0xFFFFFFFFu &&
-                              (kt_mfma ? po_kt_mfma_fold_supported(dim, selfs) : po_kt_panel_fold_supported(dim, selfs));
+        const bool can_fold = selfs != 0xFFFFFFFFu && (kt_mfma || po_kt_panel_fold_supported(dim, selfs));
         if (!(flags & PO_FLAG_NO_RC_FOLD) && can_fold) {
             uint32_t at = 0;
             rc = po_rc_fold(ctx, d_counts, d_freq, nullptr, n, dim, PO_FOLD_SELFS_FIRST, &folded, &fold_len, &at, nullptr);
@@ -570,7 +576,8 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
             if (folded) fold_src = static_cast<const uint32_t*>(ctx->ws_fold_src.p);
         }
         const uint32_t n_pairs = fold_src ? (dim - selfs) / 2 : 0;
-        rc = kt_mfma ? po_launch_kt_mfma_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, fold_src, selfs, n_pairs, &kt_plan)
+        rc = kt_mfma ? po_launch_kt_pairdot_prep(ctx, lessrank, n, dim, npad, fold_src, selfs, n_pairs,
+                                                 (flags & PO_FLAG_PAIRDOT_I8) ? 0 : 1, &kt_plan)
                      : po_launch_kt_panel_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, fold_src, fold_len, selfs, n_pairs,
                                                &kt_pplan);
         if (rc) return rc;
@@ -588,6 +595,15 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     if (metric == PO_BC && d_counts && !(flags & PO_FLAG_NO_TABLE_PATH)) {
         // same split for Bray-Curtis: equal-total record blocks with byte-sized counts take the packed SAD kernel
         rc = po_launch_bc_sad_prep(ctx, d_counts, d_totals, n, dim, npad, ctx->ws_aux.p, &cls);
+        if (rc) return rc;
+        // one common word total and few count levels per word: sum of min as a matrix-core Gram over thermometer
+        // planes (po_pairdot.hip); decided from a small header read back from the device
+        const uint32_t* p8t = nullptr;
+        uint32_t gp = 0;
+        po_bc_sad_view(ctx->ws_aux.p, npad, dim, &p8t, &gp);
+        if (!(flags & PO_FLAG_NO_PAIRDOT))
+            rc = po_launch_bc_thermo_prep(ctx, p8t, gp, cls, n, dim, npad, dbl_at, (flags & PO_FLAG_PAIRDOT_I8) ? 0 : 1,
+                                      &bc_thermo, &bc_plan, &bc_inv_n);
         if (rc) return rc;
     }
     if (stats) PO_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -624,6 +640,11 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
                 kid = cls ? PO_KERNEL_LUT_JSD : PO_KERNEL_VALU_JSD;
                 break;
             case PO_BC:
+                if (bc_thermo) {
+                    rc = po_launch_bc_thermo_tiles(ctx, a, bc_plan, bc_inv_n, &tiles);
+                    kid = PO_KERNEL_MFMA_BC;
+                    break;
+                }
                 if (cls) {
                     rc = po_launch_bc_sad_tiles(ctx, a, ctx->ws_aux.p, &tiles);
                     if (rc) return rc;
@@ -644,7 +665,7 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
                 else { rc = po_launch_gram_f64(ctx, PO_SC, a, nullptr, 0, &tiles); kid = PO_KERNEL_MFMA_F64_GRAM; }
                 break;
             case PO_KT:
-                if (kt_mfma) { rc = po_launch_kt_mfma_tiles(ctx, a, ctx->ws_freq.p, kt_plan, &tiles); kid = PO_KERNEL_MFMA_I8_KT; }
+                if (kt_mfma) { rc = po_launch_kt_pairdot_tiles(ctx, a, kt_plan, &tiles); kid = PO_KERNEL_MFMA_I8_KT; }
                 else if (kt_panel) { rc = po_launch_kt_panel_tiles(ctx, a, ctx->ws_freq.p, kt_pplan, &tiles); kid = PO_KERNEL_MFMA_I8_KT; }
                 else { rc = po_launch_kt(ctx, lessrank, n, dim, a, &tiles); kid = PO_KERNEL_VALU_KT; }
                 break;
@@ -719,8 +740,10 @@ extern "C" int po_pairwise_blocks_dev(po_ctx* ctx, const uint32_t* d_counts, con
 }
 
 // Device rows -> pageable host rows through two pinned staging buffers: the DMA of chunk c+1 runs while host
-// threads copy chunk c into the caller's memory.  (A plain hipMemcpy to pageable memory stages through one
-// runtime thread: ~11 GB/s measured on the gpurun box against ~25 GB/s this way.)
+// threads copy chunk c into the caller's memory.  Measured on the gpurun box for 6 GB (tools/ubench/d2h_paths.hip):
+// plain hipMemcpy into fresh pageable memory 18 GB/s; hipHostRegister of the destination + copy 15-17 GB/s all
+// in (registering costs 0.3 s); hipHostMalloc of a pinned result 7 GB/s all in (0.8 s to allocate, 0.5 s to free);
+// this ring into 4 KiB pages 15 GB/s, into transparent huge pages 43 GB/s (the link itself does 57 GB/s).
 static int copy_rows_to_host(po_ctx* ctx, const uint8_t* d_src, size_t src_pitch, size_t row_bytes, uint64_t rows,
                              uint8_t* dst, size_t dst_pitch) {
     const size_t kStage = 32u << 20;
@@ -730,14 +753,22 @@ static int copy_rows_to_host(po_ctx* ctx, const uint8_t* d_src, size_t src_pitch
         PO_HIP(hipStreamSynchronize(ctx->stream));
         return PO_OK;
     }
+    // A freshly allocated destination (numpy.zeros / numpy.empty: untouched anonymous pages) is first touched by the
+    // copy threads below; with 4 KiB pages that is 1.8 million page faults for a 7 GB matrix and caps the copy at
+    // ~15 GB/s.  Asking for transparent huge pages first (harmless if the range is already populated or the kernel
+    // declines) measured 43 GB/s on the same box (tools/ubench/d2h_paths.hip: ring 2 x 32 MB, 8 threads, THP).
+    {
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(dst) + 4095u) & ~(uintptr_t)4095u;
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(dst) + (rows - 1) * dst_pitch + row_bytes) & ~(uintptr_t)4095u;
+        if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
+    }
     if (!ctx->h_stage[0]) {
         PO_HIP(hipHostMalloc(&ctx->h_stage[0], kStage, hipHostMallocDefault));
         PO_HIP(hipHostMalloc(&ctx->h_stage[1], kStage, hipHostMallocDefault));
     }
     const uint64_t rows_per = kStage / row_bytes;
     const uint64_t n_chunks = (rows + rows_per - 1) / rows_per;
-    unsigned hw = std::thread::hardware_concurrency();
-    const unsigned n_thr = hw ? (hw > 8 ? 8 : hw) : 4;
+    const unsigned n_thr = po_host_threads(8);
     auto issue = [&](uint64_t c) -> hipError_t {
         const uint64_t r0 = c * rows_per, nr = (rows - r0 < rows_per) ? rows - r0 : rows_per;
         return hipMemcpy2DAsync(ctx->h_stage[c & 1], row_bytes, d_src + r0 * src_pitch, src_pitch, row_bytes, nr,

@@ -161,6 +161,12 @@ size_t po_bc_sad_workspace(uint64_t n, uint32_t dim) {
     return (size_t)bc_groups_pad(dim) * npad * sizeof(uint32_t) + npad / 128 * sizeof(unsigned long long) + 256;
 }
 
+void po_bc_sad_view(const void* ws, uint64_t npad, uint32_t dim, const uint32_t** p8t, uint32_t* groups_pad) {
+    (void)npad;
+    *p8t = static_cast<const uint32_t*>(ws);
+    *groups_pad = bc_groups_pad(dim);
+}
+
 // ws layout: packed matrix | classes | maxcount
 int po_launch_bc_sad_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
                           uint64_t npad, void* ws, const unsigned long long** cls_out) {

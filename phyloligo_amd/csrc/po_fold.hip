@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256) void rc_fold_kernel(const T* __restrict__ in, 
         __syncthreads();
         if (j == 0 && r < rows) {
             const uint64_t row = row0 + r;
-            const unsigned long long tot = totals[row], ref = totals[row & ~(uint64_t)127];
+            // "every tile belongs to the equal-total kernel" needs ONE total for the whole matrix: blocks that are
+            // uniform inside but differ from each other still leave their mixed tiles to the general kernel
+            const unsigned long long tot = totals[row], ref = totals[0];
             const bool common = tot > 0 && tot == ref;
             uint32_t bits = 0;
             if (!(common && sum_s[r] == tot && max_s[r] <= 127u)) bits |= PO_FOLD_NOT_ALL_TABLE;
@@ -124,7 +126,9 @@ __global__ __launch_bounds__(256) void rc_fold_long_kernel(const T* __restrict__
             mx = max(mx, (uint32_t)__shfl_down(mx, o, 64));
         }
         if (lane == 0) {
-            const unsigned long long tot = totals[row], ref = totals[row & ~(uint64_t)127];
+            // "every tile belongs to the equal-total kernel" needs ONE total for the whole matrix: blocks that are
+            // uniform inside but differ from each other still leave their mixed tiles to the general kernel
+            const unsigned long long tot = totals[row], ref = totals[0];
             const bool common = tot > 0 && tot == ref;
             uint32_t bits = 0;
             if (!(common && sum == tot && mx <= 127u)) bits |= PO_FOLD_NOT_ALL_TABLE;
@@ -210,9 +214,9 @@ uint32_t po_fold_selfs(uint32_t dim) {
 // symmetric.  On return *folded tells whether ws_fold holds an [n][*dim_f] matrix to use instead of the input.
 // Costs one pass over the input and one 4-byte device-to-host read (the only host synchronisation of
 // the pairwise entry points; PO_FLAG_NO_RC_FOLD skips it).
-// d_totals (may be NULL) and *flags_out (may be NULL): the same pass also tells whether every 128-record block of
-// integer counts qualifies for the equal-total fast paths (PO_FOLD_NOT_ALL_TABLE / PO_FOLD_NOT_ALL_SAD clear), so
-// that the caller can leave out the general kernel's launch.  *flags_out == 0xFFFFFFFF: nothing was checked.
+// d_totals (may be NULL) and *flags_out (may be NULL): the same pass also tells whether EVERY record has the same
+// word total (and small enough counts), i.e. whether every tile qualifies for the equal-total fast paths
+// (PO_FOLD_NOT_ALL_TABLE / PO_FOLD_NOT_ALL_SAD clear), so that the caller can leave out the general kernel's launch.  *flags_out == 0xFFFFFFFF: nothing was checked.
 int po_rc_fold(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, const uint64_t* d_totals, uint64_t n,
                uint32_t dim, uint32_t gran, bool* folded, uint32_t* dim_f, uint32_t* dbl_at, uint32_t* flags_out) {
     *folded = false;

@@ -58,6 +58,10 @@ struct po_ctx {
     po_buf ws_fold;                    // reverse-complement folded counts / frequencies (po_fold.hip) + flag word
     po_buf ws_fold_src;                // source word of every folded column, for (fold_dim, fold_gran)
     po_buf ws_recover;                 // integer profiles recovered from a frequency matrix (po_recover.hip)
+    po_buf ws_pairdot;                 // materialised operand of the pair-dot kernels (po_pairdot.hip)
+    po_buf ws_pq;                      // Kendall's word-pair table, cached per (dim, fold layout, format)
+    uint64_t pq_key = ~0ull;
+    po_buf ws_thermo;                  // Bray-Curtis thermometer plan (levels per word, element map)
     uint32_t fold_dim = 0, fold_gran = 0, fold_dim_f = 0, fold_dbl_at = 0;
     uint32_t* h_flag = nullptr;        // pinned host word for the fold decision
     void* h_stage[2] = {nullptr, nullptr};   // pinned staging buffers of the host-pointer entry points (device -> host rows)
@@ -68,6 +72,7 @@ struct po_ctx {
 };
 
 int po_buf_reserve(po_ctx* ctx, po_buf* b, size_t bytes);
+unsigned po_host_threads(unsigned cap);   // usable CPUs (affinity, cgroup quota), at most cap (po_io.cpp)
 // hipFuncAttributeMaxDynamicSharedMemorySize for `func`, raised once per context (and again only if a later
 // launch asks for more): the attribute call is host work that does not belong in a launch path
 int po_func_shmem(po_ctx* ctx, const void* func, size_t bytes);
@@ -189,18 +194,28 @@ int po_launch_ranks(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq,
 int po_launch_kt(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, const po_tile_args& a,
                  uint64_t* tiles);
 
-// Kendall on the int8 matrix cores (dim <= 256)
-bool po_kt_mfma_supported(uint32_t dim);
-bool po_kt_mfma_fold_supported(uint32_t dim, uint32_t n_selfs);
-size_t po_kt_mfma_workspace(uint64_t n, uint32_t dim);
-struct po_kt_mfma_plan {
-    uint32_t n_items, words, row_bytes, dbl1, dbl2;
-    uint32_t pwaves;        // producer waves of the 16-wave workgroup: 8 or 12
-    uint32_t ksteps;        // K-steps of 32 word pairs per round (per workgroup barrier): 4 or 6
+// Kendall / Bray-Curtis as exact Gram matrices over a materialised {-1,0,1} operand (po_pairdot.hip)
+struct po_pairdot_plan {
+    int fmt_fp4;            // operand format: 0 = int8 (16 elements per 16-byte chunk), 1 = FP4 E2M1 (32)
+    uint32_t n_stages;      // stages of 8 chunks
+    uint32_t dbl1, dbl2;    // stages before which the accumulators double (weight classes), PO_NO_DOUBLING = never
+    uint64_t op_n;          // records per chunk row of the operand (n rounded up to the 256-record tile)
+    uint64_t k_elems;       // K (KT: padded; BC: thermometer planes before padding)
+    size_t aux_offset;      // BC: where the per-record count sums sit inside ws_thermo
 };
-int po_launch_kt_mfma_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, uint64_t npad, void* ws,
-                           const uint32_t* fold_src, uint32_t n_selfs, uint32_t n_pairs, po_kt_mfma_plan* plan);
-int po_launch_kt_mfma_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, const po_kt_mfma_plan& plan, uint64_t* tiles);
+bool po_kt_pairdot_supported(uint32_t dim);
+size_t po_kt_pairdot_rank_bytes(uint64_t n, uint32_t dim);
+size_t po_kt_pairdot_operand_bytes(uint64_t n, uint32_t dim, int fmt_fp4);
+int po_launch_kt_pairdot_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, uint64_t npad,
+                              const uint32_t* fold_src, uint32_t n_selfs, uint32_t n_pairs, int fmt_fp4,
+                              po_pairdot_plan* plan);
+int po_launch_kt_pairdot_tiles(po_ctx* ctx, const po_tile_args& a, const po_pairdot_plan& plan, uint64_t* tiles);
+// Bray-Curtis on thermometer planes; p8t / groups_pad / cls from the SAD prep (po_bc_sad_view)
+void po_bc_sad_view(const void* ws, uint64_t npad, uint32_t dim, const uint32_t** p8t, uint32_t* groups_pad);
+int po_launch_bc_thermo_prep(po_ctx* ctx, const uint32_t* p8t, uint32_t groups_pad, const unsigned long long* cls, uint64_t n,
+                             uint32_t dim, uint64_t npad, uint32_t dbl_at, int fmt_fp4, bool* eligible, po_pairdot_plan* plan,
+                             double* inv_n);
+int po_launch_bc_thermo_tiles(po_ctx* ctx, const po_tile_args& a, const po_pairdot_plan& plan, double inv_n, uint64_t* tiles);
 
 // Kendall on the int8 matrix cores, 256 < dim <= 16384: 64-word rank panels (po_kt_panel.hip)
 bool po_kt_panel_supported(uint32_t dim);

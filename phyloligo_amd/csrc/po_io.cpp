@@ -25,7 +25,32 @@
 
 #include "phyloligo_amd.h"
 
+#include <sched.h>
+
 void po_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+// Host threads worth starting: the CPUs this process may run on (affinity mask), cut down to the cgroup-v2 CPU quota
+// when there is one (a GPU box shows every hardware thread of the host but gives a job a share of them), at most `cap`.
+unsigned po_host_threads(unsigned cap) {
+    static const unsigned usable = []() -> unsigned {
+        unsigned n = 0;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = (unsigned)CPU_COUNT(&set);
+        if (n == 0) n = std::thread::hardware_concurrency();
+        if (n == 0) n = 4;
+        if (FILE* fh = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32];
+            double period = 0.0;
+            if (fscanf(fh, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0.0) {
+                const double cpus = atof(q) / period;
+                if (cpus >= 1.0 && cpus < (double)n) n = (unsigned)(cpus + 0.5);
+            }
+            fclose(fh);
+        }
+        return n;
+    }();
+    return usable < cap ? usable : (cap ? cap : 1u);
+}
 
 namespace {
 
@@ -88,9 +113,7 @@ int fasta_parallel(const uint8_t* data, uint64_t len, uint8_t* seq_out, uint64_t
     int rc = fasta_walk(data, 0, first, false, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (rc) return rc;
 
-    unsigned hw = std::thread::hardware_concurrency();
-    uint64_t nseg = hw ? hw : 4;
-    if (nseg > 32) nseg = 32;
+    uint64_t nseg = po_host_threads(32);
     const uint64_t body = len - first;
     if (body / (4u << 20) + 1 < nseg) nseg = body / (4u << 20) + 1;   // at least 4 MiB per thread
     std::vector<uint64_t> cut(nseg + 1, len);
@@ -190,8 +213,7 @@ extern "C" int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, 
     int rc = PO_OK;
     if (rows && cols) {
         // rows are formatted by a pool of host threads, a slab of rows each, and written in order
-        unsigned hw = std::thread::hardware_concurrency();
-        const unsigned nthreads = (rows * cols < (1u << 16)) ? 1u : (hw == 0 ? 4u : (hw > 32u ? 32u : hw));
+        const unsigned nthreads = (rows * cols < (1u << 16)) ? 1u : po_host_threads(32);
         const uint64_t slab = std::max<uint64_t>(1, std::min<uint64_t>((rows + nthreads - 1) / nthreads, (4u << 20) / (cols * 25 + 1) + 1));
         std::vector<std::vector<char>> bufs(nthreads);
         for (uint64_t base = 0; base < rows && rc == PO_OK; base += slab * nthreads) {

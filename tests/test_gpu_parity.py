@@ -309,8 +309,30 @@ def test_kt_mfma_and_valu_kernels_agree(ctx):
         assert st["kernel_id"] == 8 and st2["kernel_id"] == 5
         assert np.array_equal(fast, slow)
         assert np.array_equal(fast, fast.T)
+        assert np.array_equal(fast, ctx.pairwise(counts, totals, "KT", pairdot_i8=True))     # FP4 and int8 operands: same integers
         if pattern in ("111", "11"):
             oc, ot = po.compute_counts(contigs, pattern, "both")
             want = po.pairwise_block(po.counts_to_frequencies(oc, ot), "KT")
             np.testing.assert_allclose(fast, want, rtol=RTOL, atol=ATOL)
         np.testing.assert_array_equal(ctx.pairwise(counts, totals, "KT", row_begin=3, row_end=140), fast[3:140])
+
+
+@pytest.mark.parametrize("strand", ["both", "plus"])
+def test_kt_pairdot_several_tiles(ctx, strand):
+    """The materialised pair-sign Gram over more than one 256-record tile, folded (both strands: weight classes
+    4/2/1 with accumulator doubling) and unfolded (plus strand: all 32 640 word pairs of k = 4), FP4 and int8
+    operands, float32 output, row blocks that do not start on a tile edge - all bit-identical to the O(D^2) VALU kernel."""
+    contigs = _random_assembly(701, 77, lo=300, hi=3000)
+    contigs[13] = contigs[400]                       # duplicates -> tau exactly 1
+    contigs[650] = b"ACGT" * 100                     # heavy ties
+    seq, offsets = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, offsets, "1111", strand)
+    fast, st = ctx.pairwise(counts, totals, "KT", want_stats=True)
+    valu = ctx.pairwise(counts, totals, "KT", table_path=False)
+    assert st["kernel_id"] == 8 and bool(st["rc_folded"]) == (strand == "both")
+    assert np.array_equal(fast, valu)
+    assert np.array_equal(fast, ctx.pairwise(counts, totals, "KT", pairdot_i8=True))
+    assert fast[13, 400] == 1.0 and np.all(np.diag(fast) == 1.0)
+    np.testing.assert_array_equal(ctx.pairwise(counts, totals, "KT", row_begin=130, row_end=517), fast[130:517])
+    f32 = ctx.pairwise(counts, totals, "KT", dtype="float32")
+    assert np.array_equal(f32, fast.astype(np.float32))
