@@ -175,13 +175,7 @@ __global__ __launch_bounds__(kThreads) void kt_tile_kernel(const uint32_t* __res
     const double T = 0.5 * (double)A.dim * ((double)A.dim - 1.0);
     const double* ties = A.rowstat + 3 * A.npad;
     const double dx = T - ties[j], dy = T - ties[i];     // con+dis+exx, con+dis+exy
-    double v;
-    if (dx == 0.0 || dy == 0.0) {
-        v = 1.0 - 1.0;
-    } else {
-        const double tau = (double)S / sqrt(dx * dy);
-        v = 1.0 - (1.0 - tau);
-    }
+    const double v = po_kt_value((double)S, dy, dx, po_kt_rs(dy), po_kt_rs(dx));
     po_store_pair<OUT>(A, i, j, v, po_tile_mirrors(A, ti, tj));
 }
 

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(kThreads, 4) void kt_panel_tile_kernel(po_tile_args
     double* wl = reinterpret_cast<double*>(smem) + cw_ * (32 * 33);            // 8 consumer waves x 8.4 KiB
     const uint64_t c = cj + lr;
     const double dc = T - ties[min(c, A.npad - 1)];
+    const double rsc = po_kt_rs(dc);
     double drs[2][16];                                     // every load before the first store (shared in-order vmcnt)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -247,13 +248,7 @@ __global__ __launch_bounds__(kThreads, 4) void kt_panel_tile_kernel(po_tile_args
             const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             const uint64_t rr = ri + m * 32 + rl;
             const double dr = drs[m][reg];
-            double v;
-            if (dr == 0.0 || dc == 0.0) {
-                v = 1.0 - 1.0;
-            } else {
-                const double tau = (double)g[m][reg] / sqrt(dr * dc);
-                v = 1.0 - (1.0 - tau);
-            }
+            const double v = po_kt_value((double)g[m][reg], dr, dc, po_kt_rs(dr), rsc);
             if (c_ok && rr >= A.row_begin && rr < n_rows) out[(rr - A.row_begin) * A.ld_out + (c - A.col_begin)] = (OUT)v;
             if (mirror) wl[lr * 33 + rl] = v;
         }

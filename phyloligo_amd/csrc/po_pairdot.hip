@@ -35,14 +35,17 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int TE = 256;                             // tile edge (records)
-constexpr int kThreads = 512;                       // 8 waves: 2 x 4 blocks of 128 x 64 pairs
-constexpr int SCH = 8;                              // 16-byte K-chunks per stage = 4 MFMA k-steps
-constexpr int kChunkRow = 2 * TE * 16;              // one chunk of the tile's 256 row + 256 column records (8 KiB)
-constexpr int kStageBytes = SCH * kChunkRow;        // 64 KiB, double buffered
+constexpr int TE = 256;                             // tile edge (records): the unit of the tile order and of the operand padding
+constexpr int TR = 128;                             // rows per workgroup: a tile is split between two workgroups (halves), so
+                                                    // that two of them fit a CU and one's epilogue overlaps the other's Gram
+constexpr int kThreads = 256;                       // 4 waves of 128 x 64 pairs
+constexpr int SCH = 4;                              // 16-byte K-chunks per stage = 2 MFMA k-steps
+constexpr int kChunkRow = (TR + TE) * 16;           // one chunk of the half tile's 128 row + 256 column records (6 KiB)
+constexpr int kStageBytes = SCH * kChunkRow;        // 24 KiB, double buffered
+constexpr int kPieces = SCH * (TR + TE) / 64;       // 1 KiB LDS-DMA instructions per stage
 constexpr int kTrStride = 33;
-constexpr int kMirrorBytes = 8 * 32 * kTrStride * 8;   // wave-private 32 x 32 transposes of the epilogue
-constexpr int kTermBytes = 2 * 2 * TE * 8;          // two per-record terms for the tile's rows and columns
+constexpr int kMirrorBytes = 4 * 32 * kTrStride * 8;   // wave-private 32 x 32 transposes of the epilogue
+constexpr int kTermBytes = 2 * (TR + TE) * 8;       // two per-record terms for the half tile's rows and columns
 
 enum { FMT_I8 = 0, FMT_FP4 = 1 };
 enum { EPI_KT = 0, EPI_BC = 1 };
@@ -60,19 +63,23 @@ struct pd_epilogue {
 };
 
 // ---- the tile kernel -----------------------------------------------------------------------------------------
+// Workgroup b: logical position L in the XCD-aware order of 2 x (number of 256 x 256 tiles); tile L / 2, rows
+// [128 (L & 1), +128) of it.  The two halves of a tile are neighbours in that order: same XCD, same time, so the
+// column operand they share comes out of the L2 once.
 template <int FMT, int EPI, typename OUT>
 __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args A, const uint8_t* __restrict__ op,
                                                                    uint64_t op_n, uint32_t n_stages, uint32_t dbl1,
                                                                    uint32_t dbl2, pd_epilogue E) {
     typedef typename acc_t<FMT>::type ACC;
-    extern __shared__ __align__(16) unsigned char smem[];   // [2][SCH][rows 256 | cols 256][16 B]; epilogue scratch afterwards
+    extern __shared__ __align__(16) unsigned char smem[];   // [2][SCH][rows 128 | cols 256][16 B]; epilogue scratch afterwards
     const uint32_t t = threadIdx.x;
-    const uint32_t lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const uint32_t wr = wave >> 2, wc = wave & 3;          // 2 x 4 waves of 128 x 64
+    const uint32_t lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave = its 64-column block
     const uint32_t lr = lane & 31, lh = lane >> 5;
     uint32_t ti, tj;
-    po_tile_coords(A, TE, blockIdx.x, ti, tj);
-    const uint64_t i0 = (uint64_t)ti * TE, j0 = (uint64_t)tj * TE;
+    const uint64_t L = po_xcd_swizzle(blockIdx.x, gridDim.x);
+    po_tile_coords_logical(A, TE, L >> 1, ti, tj);
+    const uint64_t i0 = (uint64_t)ti * TE + (L & 1) * TR, j0 = (uint64_t)tj * TE;
+    if (i0 >= min(A.row_end, A.n) || i0 + TR <= A.row_begin) return;     // a half with no row of the block (ragged edges)
 
     ACC g[4][2];
 #pragma unroll
@@ -82,14 +89,14 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
 #pragma unroll
             for (int e = 0; e < 16; ++e) g[m][nn][e] = 0;
 
-    // wave w stages chunk w of the stage: 8 one-KiB LDS-DMA instructions (4 x 64 row records, 4 x 64 column records)
+    // a stage is kPieces one-KiB LDS-DMA instructions (per chunk: 2 x 64 row records, 4 x 64 column records), dealt to the waves
     auto issue = [&](uint32_t stage, uint32_t buf) {
-        const uint8_t* src = op + (uint64_t)(stage * SCH + wave) * op_n * 16;
-        unsigned char* dst = smem + buf * kStageBytes + wave * kChunkRow;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const uint64_t rec = (p < 4 ? i0 + p * 64 : j0 + (p - 4) * 64) + lane;
-            po_glds16(src + rec * 16, dst + p * 1024);
+        for (int u = 0; u < kPieces / 4; ++u) {
+            const uint32_t idx = wave * (kPieces / 4) + u;              // wave uniform
+            const uint32_t ch = idx / 6, p = idx % 6;
+            const uint64_t rec = (p < 2 ? i0 + p * 64 : j0 + (p - 2) * 64) + lane;
+            po_glds16(op + ((uint64_t)(stage * SCH + ch) * op_n + rec) * 16, smem + buf * kStageBytes + ch * kChunkRow + p * 1024);
         }
     };
     auto compute = [&](uint32_t buf) {
@@ -98,9 +105,9 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
             const unsigned char* base = smem + buf * kStageBytes + (2 * s + lh) * kChunkRow;   // lane halves: the two chunks of a k-step
             v4i a[4], b[2];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4i*>(base + (wr * 128 + m * 32 + lr) * 16);
+            for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4i*>(base + (m * 32 + lr) * 16);
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn) b[nn] = *reinterpret_cast<const v4i*>(base + (TE + wc * 64 + nn * 32 + lr) * 16);
+            for (int nn = 0; nn < 2; ++nn) b[nn] = *reinterpret_cast<const v4i*>(base + (TR + wave * 64 + nn * 32 + lr) * 16);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -141,21 +148,27 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
     // ---- epilogue --------------------------------------------------------------------------------------------
     // per-record terms into LDS first: on gfx9 loads and stores share the in-order vmcnt, a global load issued among
     // the output stores could only be waited for together with every store before it
-    double* terms = reinterpret_cast<double*>(smem + kMirrorBytes);     // [term0: rows 256 | cols 256][term1: rows | cols]
-    {
-        const uint64_t rec = min((t < TE) ? i0 + t : j0 + (t - TE), A.npad - 1);
-        terms[t] = E.term0[rec];
-        terms[2 * TE + t] = (EPI == EPI_BC) ? E.term1[rec] : 0.0;
+    double* terms = reinterpret_cast<double*>(smem + kMirrorBytes);     // [term0: rows 128 | cols 256][term1: rows | cols]
+    for (uint32_t x = t; x < TR + TE; x += kThreads) {
+        const uint64_t rec = min((x < TR) ? i0 + x : j0 + (x - TR), A.npad - 1);
+        if (EPI == EPI_KT) {                 // d = T - ties (word pairs not tied in the record) and 1/sqrt(d), once per record
+            const double d = E.scalar - E.term0[rec];
+            terms[x] = d;
+            terms[TR + TE + x] = po_kt_rs(d);
+        } else {
+            terms[x] = E.term0[rec];
+            terms[TR + TE + x] = E.term1[rec];
+        }
     }
     __syncthreads();
     OUT* out = static_cast<OUT*>(A.out);
     OUT* mir = static_cast<OUT*>(A.mirror);
     const bool mirror = po_tile_mirrors(A, ti, tj);
     const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
-    const uint64_t iw = i0 + wr * 128, jw = j0 + wc * 64;
+    const uint64_t iw = i0, jw = j0 + wave * 64;
     double* wl = reinterpret_cast<double*>(smem) + wave * (32 * kTrStride);
-    const double* r0t = terms + wr * 128, *c0t = terms + TE + wc * 64;
-    const double* r1t = terms + 2 * TE + wr * 128, *c1t = terms + 3 * TE + wc * 64;
+    const double* r0t = terms, *c0t = terms + TR + wave * 64;
+    const double* r1t = terms + TR + TE, *c1t = terms + TR + TE + TR + wave * 64;
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
         const uint64_t c = jw + nn * 32 + lr;
@@ -169,14 +182,8 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
                 const uint64_t r = iw + m * 32 + rl;
                 const double G = (double)g[m][nn][reg];
                 double v;
-                if (EPI == EPI_KT) {          // tau = S / sqrt((T - t_r)(T - t_c)); KT = 1 - (1 - tau), 0 when a factor vanishes
-                    const double dr = E.scalar - r0t[m * 32 + rl], dc = E.scalar - tc0;
-                    if (dr == 0.0 || dc == 0.0) {
-                        v = 1.0 - 1.0;
-                    } else {
-                        const double tau = G / sqrt(dr * dc);
-                        v = 1.0 - (1.0 - tau);
-                    }
+                if (EPI == EPI_KT) {          // po_tiles.h: tau = S * (rs_r rs_c), KT = 1 - (1 - tau), 0 when a factor vanishes
+                    v = po_kt_value(G, r0t[m * 32 + rl], tc0, r1t[m * 32 + rl], tc1);
                 } else {                      // BC = (sum |ca - cb| / n) / (w_a + w_b),  sum |ca - cb| = s_a + s_b - 2 sum min
                     const double num = (r1t[m * 32 + rl] + tc1) - 2.0 * G;      // exact integers
                     v = (r == c) ? 0.0 : (num * E.scalar) / (r0t[m * 32 + rl] + tc0);
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(256) void kt_expand_kernel(const uint8_t* __restric
 template <int FMT, int EPI>
 int launch_tiles(po_ctx* ctx, const po_tile_args& a, const uint8_t* op, uint64_t op_n, uint32_t n_stages, uint32_t dbl1,
                  uint32_t dbl2, const pd_epilogue& E, uint64_t* tiles) {
-    const uint64_t nblocks = po_tile_count(a, TE);
+    const uint64_t nblocks = 2 * po_tile_count(a, TE);             // two workgroups (row halves) per tile
     if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }

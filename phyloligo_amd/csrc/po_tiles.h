@@ -58,6 +58,29 @@ __device__ __forceinline__ double po_sqrt_nonneg(double x) {
     return x == 0.0 ? 0.0 : g;
 }
 
+// ---- Kendall's tau from S = con - dis and the per-record factors (shared by every Kendall kernel so that they
+// agree bit for bit).  d = T - t = the number of word pairs NOT tied in the record (an integer);
+//     tau = S / sqrt(d_r d_c) = S * (rs_r * rs_c),   rs = 1 / sqrt(d)  (0 for d = 0: the reference returns
+// distance 1, i.e. KT 0, when a factor vanishes).  The product of the two per-record terms is formed first, so
+// the value does not depend on which record is the row; S == d_r == d_c (same order, same ties) is exactly 1.
+// KT = 1 - (1 - tau) as in phylodist.KT (1 - distance).  An f64 sqrt and a divide per matrix entry (about 50
+// instructions) measured as much vector time as the whole matrix-core Gram of po_pairdot.hip; this is 6.
+__device__ __forceinline__ double po_kt_rs(double d) {            // 1/sqrt(d): v_rsq_f64 seed + two Newton steps
+    double y = __builtin_amdgcn_rsq(d);
+    y = fma(0.5 * y, fma(-(d * y), y, 1.0), y);
+    y = fma(0.5 * y, fma(-(d * y), y, 1.0), y);
+    return d > 0.0 ? y : 0.0;
+}
+__device__ __forceinline__ double po_kt_value(double S, double dr, double dc, double rsr, double rsc) {
+    double tau = S * (rsr * rsc);
+    tau = fmin(fmax(tau, -1.0), 1.0);
+    if (dr == dc && dr > 0.0) {
+        if (S == dr) tau = 1.0;
+        if (-S == dr) tau = -1.0;
+    }
+    return 1.0 - (1.0 - tau);
+}
+
 // linear id -> tile of the upper triangle of a T x T tile grid (tj >= ti), row major
 __device__ __forceinline__ void po_tri_decode(uint64_t b, uint32_t T, uint32_t& ti, uint32_t& tj) {
     const double tt = 2.0 * T + 1.0;
@@ -114,23 +137,30 @@ __device__ __forceinline__ void po_tri_band_decode(uint64_t L, uint32_t T, uint3
     }
 }
 
-// absolute tile indices of workgroup `b`
-__device__ __forceinline__ void po_tile_coords(const po_tile_args& A, uint32_t edge, uint64_t b, uint32_t& ti, uint32_t& tj) {
+// absolute tile indices of logical position L in the block's tile order (see po_xcd_swizzle)
+__device__ __forceinline__ void po_tile_coords_logical(const po_tile_args& A, uint32_t edge, uint64_t L, uint32_t& ti, uint32_t& tj) {
     const uint32_t r0 = (uint32_t)(A.row_begin / edge), r1 = (uint32_t)((A.row_end + edge - 1) / edge);
     const uint32_t c0 = (uint32_t)(A.col_begin / edge), c1 = (uint32_t)((A.col_end + edge - 1) / edge);
     if (A.triangular) {
         const uint32_t T = r1 - r0;
-        po_tri_band_decode(po_xcd_swizzle(b, (uint64_t)T * (T + 1) / 2), T, ti, tj);
+        po_tri_band_decode(L, T, ti, tj);
         ti += r0;
         tj += r0;
     } else {
         const uint64_t tr = r1 - r0, tc = c1 - c0;
-        const uint64_t L = po_xcd_swizzle(b, tr * tc);
         const uint64_t band = L / (kBand * tc), l = L % (kBand * tc);
         const uint64_t Se = (tr - band * kBand < kBand) ? (tr - band * kBand) : kBand;
         ti = r0 + (uint32_t)(band * kBand + l % Se);
         tj = c0 + (uint32_t)(l / Se);
     }
+}
+
+// absolute tile indices of workgroup `b`
+__device__ __forceinline__ void po_tile_coords(const po_tile_args& A, uint32_t edge, uint64_t b, uint32_t& ti, uint32_t& tj) {
+    const uint32_t r0 = (uint32_t)(A.row_begin / edge), r1 = (uint32_t)((A.row_end + edge - 1) / edge);
+    const uint32_t c0 = (uint32_t)(A.col_begin / edge), c1 = (uint32_t)((A.col_end + edge - 1) / edge);
+    const uint64_t total = A.triangular ? (uint64_t)(r1 - r0) * (r1 - r0 + 1) / 2 : (uint64_t)(r1 - r0) * (c1 - c0);
+    po_tile_coords_logical(A, edge, po_xcd_swizzle(b, total), ti, tj);
 }
 
 __device__ __forceinline__ bool po_in_block(const po_tile_args& A, uint64_t i, uint64_t j) {
