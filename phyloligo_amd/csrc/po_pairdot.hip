@@ -36,15 +36,19 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int TE = 256;                             // tile edge (records): the unit of the tile order and of the operand padding
-constexpr int TR = 128;                             // rows per workgroup: a tile is split between two workgroups (halves), so
-                                                    // that two of them fit a CU and one's epilogue overlaps the other's Gram
-constexpr int kThreads = 256;                       // 4 waves of 128 x 64 pairs
+constexpr int TR = 256;                             // rows per workgroup (128: a tile is split between two workgroups)
+constexpr int kHalves = TE / TR;
+constexpr int kWaves = 4 * (TR / 128);              // each wave 128 x 64 pairs: TR / 128 rows of 4 waves
+constexpr int kThreads = 64 * kWaves;
 constexpr int SCH = 4;                              // 16-byte K-chunks per stage = 2 MFMA k-steps
 constexpr int kChunkRow = (TR + TE) * 16;           // one chunk of the half tile's 128 row + 256 column records (6 KiB)
-constexpr int kStageBytes = SCH * kChunkRow;        // 24 KiB, double buffered
+constexpr int kStageBytes = SCH * kChunkRow;        // 24 KiB
+constexpr int NBUF = 3;                             // stage ring: two stages in flight beside the one being consumed
 constexpr int kPieces = SCH * (TR + TE) / 64;       // 1 KiB LDS-DMA instructions per stage
 constexpr int kTrStride = 33;
-constexpr int kMirrorBytes = 4 * 32 * kTrStride * 8;   // wave-private 32 x 32 transposes of the epilogue
+constexpr int kMirrorBytes = kWaves * 32 * kTrStride * 8;   // wave-private 32 x 32 transposes of the epilogue
+constexpr int kPerWave = kPieces / kWaves;          // LDS-DMA instructions per wave and stage
+static_assert(kPieces % kWaves == 0, "pieces are dealt evenly to the waves");
 constexpr int kTermBytes = 2 * (TR + TE) * 8;       // two per-record terms for the half tile's rows and columns
 
 enum { FMT_I8 = 0, FMT_FP4 = 1 };
@@ -71,14 +75,15 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
                                                                    uint64_t op_n, uint32_t n_stages, uint32_t dbl1,
                                                                    uint32_t dbl2, pd_epilogue E) {
     typedef typename acc_t<FMT>::type ACC;
-    extern __shared__ __align__(16) unsigned char smem[];   // [2][SCH][rows 128 | cols 256][16 B]; epilogue scratch afterwards
+    extern __shared__ __align__(16) unsigned char smem[];   // ring [NBUF][SCH][rows 128 | cols 256][16 B]; epilogue scratch afterwards
     const uint32_t t = threadIdx.x;
-    const uint32_t lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // wave = its 64-column block
+    const uint32_t lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t wave = wv & 3, wr = wv >> 2;            // its 64-column block, its 128-row block
     const uint32_t lr = lane & 31, lh = lane >> 5;
     uint32_t ti, tj;
     const uint64_t L = po_xcd_swizzle(blockIdx.x, gridDim.x);
-    po_tile_coords_logical(A, TE, L >> 1, ti, tj);
-    const uint64_t i0 = (uint64_t)ti * TE + (L & 1) * TR, j0 = (uint64_t)tj * TE;
+    po_tile_coords_logical(A, TE, L / kHalves, ti, tj);
+    const uint64_t i0 = (uint64_t)ti * TE + (L % kHalves) * TR, j0 = (uint64_t)tj * TE;
     if (i0 >= min(A.row_end, A.n) || i0 + TR <= A.row_begin) return;     // a half with no row of the block (ragged edges)
 
     ACC g[4][2];
@@ -90,13 +95,15 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
             for (int e = 0; e < 16; ++e) g[m][nn][e] = 0;
 
     // a stage is kPieces one-KiB LDS-DMA instructions (per chunk: 2 x 64 row records, 4 x 64 column records), dealt to the waves
-    auto issue = [&](uint32_t stage, uint32_t buf) {
+    auto issue = [&](uint32_t stage) {
+        unsigned char* dst = smem + (stage % NBUF) * kStageBytes;
 #pragma unroll
-        for (int u = 0; u < kPieces / 4; ++u) {
-            const uint32_t idx = wave * (kPieces / 4) + u;              // wave uniform
-            const uint32_t ch = idx / 6, p = idx % 6;
-            const uint64_t rec = (p < 2 ? i0 + p * 64 : j0 + (p - 2) * 64) + lane;
-            po_glds16(op + ((uint64_t)(stage * SCH + ch) * op_n + rec) * 16, smem + buf * kStageBytes + ch * kChunkRow + p * 1024);
+        for (int u = 0; u < kPerWave; ++u) {
+            constexpr uint32_t ppc = (TR + TE) / 64;                    // pieces per chunk: TR / 64 of rows, 4 of columns
+            const uint32_t idx = wv * kPerWave + u;                     // wave uniform
+            const uint32_t ch = idx / ppc, p = idx % ppc;
+            const uint64_t rec = (p < TR / 64 ? i0 + p * 64 : j0 + (p - TR / 64) * 64) + lane;
+            po_glds16(op + ((uint64_t)(stage * SCH + ch) * op_n + rec) * 16, dst + ch * kChunkRow + p * 1024);
         }
     };
     auto compute = [&](uint32_t buf) {
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
             const unsigned char* base = smem + buf * kStageBytes + (2 * s + lh) * kChunkRow;   // lane halves: the two chunks of a k-step
             v4i a[4], b[2];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4i*>(base + (m * 32 + lr) * 16);
+            for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4i*>(base + (wr * 128 + m * 32 + lr) * 16);
 #pragma unroll
             for (int nn = 0; nn < 2; ++nn) b[nn] = *reinterpret_cast<const v4i*>(base + (TR + wave * 64 + nn * 32 + lr) * 16);
 #pragma unroll
@@ -132,16 +139,25 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
                 for (int e = 0; e < 16; ++e) g[m][nn][e] = g[m][nn][e] + g[m][nn][e];
     };
 
-    if (n_stages) issue(0, 0);
-    __syncthreads();                                       // drains the LDS-DMA (vmcnt) of every wave
+    // Stage st + 2 is issued while stage st is consumed: a stage of two k-steps is ~0.25-0.5 us of matrix-core work,
+    // an LDS-DMA from L2 / Infinity Cache takes longer than that under load, so one stage of look-ahead left the waves
+    // parked at the barrier for more than half of the loop (SQ_WAIT_ANY 55 %).  A wave waits for its OWN LDS-DMA with a
+    // counted vmcnt (kPieces / 4 = 6 instructions per stage: the younger stage stays in flight), then one raw s_barrier
+    // per stage says that every wave's part of stage st has landed and that stage st - 1 has been consumed by all.
+    static_assert(kPerWave == 6 || kPerWave == 4, "the counted waits below know 6 and 4 LDS-DMA instructions per wave and stage");
+    if (n_stages > 0) issue(0);
+    if (n_stages > 1) issue(1);
     for (uint32_t st = 0; st < n_stages; ++st) {
-        const uint32_t buf = st & 1;
-        if (st + 1 < n_stages) issue(st + 1, buf ^ 1);     // lands while this stage feeds the matrix cores
+        if (st + 1 >= n_stages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (kPerWave == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (st + 2 < n_stages) issue(st + 2);              // into the slot stage st - 1 has just left
         if (st == dbl1) double_sums();
         if (st == dbl2) double_sums();
-        compute(buf);
-        __syncthreads();
+        compute(st % NBUF);
     }
+    __syncthreads();                                       // the ring becomes the epilogue's scratch
     if (dbl1 != PO_NO_DOUBLING && dbl1 >= n_stages) double_sums();
     if (dbl2 != PO_NO_DOUBLING && dbl2 >= n_stages) double_sums();
 
@@ -165,10 +181,10 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
     OUT* mir = static_cast<OUT*>(A.mirror);
     const bool mirror = po_tile_mirrors(A, ti, tj);
     const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
-    const uint64_t iw = i0, jw = j0 + wave * 64;
-    double* wl = reinterpret_cast<double*>(smem) + wave * (32 * kTrStride);
-    const double* r0t = terms, *c0t = terms + TR + wave * 64;
-    const double* r1t = terms + TR + TE, *c1t = terms + TR + TE + TR + wave * 64;
+    const uint64_t iw = i0 + wr * 128, jw = j0 + wave * 64;
+    double* wl = reinterpret_cast<double*>(smem) + wv * (32 * kTrStride);
+    const double* r0t = terms + wr * 128, *c0t = terms + TR + wave * 64;
+    const double* r1t = terms + TR + TE + wr * 128, *c1t = terms + TR + TE + TR + wave * 64;
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
         const uint64_t c = jw + nn * 32 + lr;
@@ -254,12 +270,12 @@ __global__ __launch_bounds__(256) void kt_expand_kernel(const uint8_t* __restric
 template <int FMT, int EPI>
 int launch_tiles(po_ctx* ctx, const po_tile_args& a, const uint8_t* op, uint64_t op_n, uint32_t n_stages, uint32_t dbl1,
                  uint32_t dbl2, const pd_epilogue& E, uint64_t* tiles) {
-    const uint64_t nblocks = 2 * po_tile_count(a, TE);             // two workgroups (row halves) per tile
+    const uint64_t nblocks = kHalves * po_tile_count(a, TE);       // kHalves workgroups (row blocks of TR records) per tile
     if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
-    const size_t shmem = 2 * (size_t)kStageBytes;
-    static_assert(kMirrorBytes + kTermBytes <= 2 * kStageBytes, "epilogue scratch must fit the staging area");
+    const size_t shmem = NBUF * (size_t)kStageBytes;
+    static_assert(kMirrorBytes + kTermBytes <= NBUF * kStageBytes, "epilogue scratch must fit the staging area");
     if (a.out_f32) {
         auto k = pairdot_tile_kernel<FMT, EPI, float>;
         PO_SHMEM(ctx, k, shmem);

@@ -86,7 +86,7 @@ def test_equal_total_blocks_with_ragged_edges(ctx, metric):
     oc, ot = po.compute_counts(contigs, "1111", "both")
     want = po.pairwise_block(po.counts_to_frequencies(oc, ot), metric)
     got, st = ctx.pairwise(counts, totals, metric, want_stats=True)
-    assert st["kernel_id"] in (4, 6, 7)
+    assert st["kernel_id"] in (4, 6, 7, 9)      # 9: BC on thermometer planes (few count levels per word)
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
     assert np.array_equal(got, got.T)
     for lo, hi in ((0, 1), (5, 133), (127, 300), (299, 300)):

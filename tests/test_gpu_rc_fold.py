@@ -97,7 +97,7 @@ def test_equal_totals_table_kernels_fold(ctx, metric):
         counts, totals = ctx.count_profiles(seq, off, pattern, "both")
         folded, st = ctx.pairwise(counts, totals, metric, want_stats=True)
         plain, st0 = ctx.pairwise(counts, totals, metric, want_stats=True, rc_fold=False)
-        assert st["rc_folded"] and st["kernel_id"] == st0["kernel_id"] and st["kernel_id"] in (6, 7)
+        assert st["rc_folded"] and st["kernel_id"] in (6, 7, 9) and st0["kernel_id"] in (6, 7, 9)
         np.testing.assert_allclose(folded, plain, rtol=1e-9, atol=2e-11)
         freq = counts / totals[:, None].astype(np.float64)
         rows = [0, 1, 57, 399]
@@ -165,11 +165,12 @@ def test_long_rows_fold_without_lds_staging(ctx):
         np.testing.assert_allclose(folded, oracle.pairwise_block(freq, metric), rtol=RTOL, atol=ATOL, equal_nan=True)
 
 
-@pytest.mark.parametrize("pattern,expect_fold", [("1111", True), ("111", True), ("1", True), ("11", False), ("1001", False),
-                                                 ("101", False), ("11011", True), ("1101", False)])
+@pytest.mark.parametrize("pattern,expect_fold", [("1111", True), ("111", True), ("1", True), ("11", True), ("1001", True),
+                                                 ("101", True), ("11011", True), ("1101", False)])
 def test_kendall_folds_exactly(ctx, pattern, expect_fold):
     """Kendall's S is an integer: the weighted sum over orbit representatives must reproduce the full sum bit for bit.
-    k = 2 (4 self-paired words: the 16-word blocks would straddle the regions) and k > 4 (no int8 kernel) do not fold."""
+    Every palindromic pattern folds (the materialised pair-sign operand orders its word pairs by weight class, whatever
+    the number of self-paired words); a pattern that does not read the same in both directions does not."""
     contigs = contigs_ragged(140, 31, lo=200, hi=1500)
     seq, off = pack(contigs)
     counts, totals = ctx.count_profiles(seq, off, pattern, "both")
