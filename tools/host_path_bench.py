@@ -9,9 +9,11 @@ ctx = pa.Context(0)
 seq, off = synthetic.contig_bytes(n, 2000, seed=50001)
 pairs = n * (n - 1) / 2
 for metric in ("JSD", "Eucl"):
-    for it in range(2):
+    t2 = 1e9
+    for it in range(3):
         t = time.perf_counter(); counts, totals = ctx.count_profiles(seq, off, "1111", "both"); t1 = time.perf_counter() - t
-        t = time.perf_counter(); m = ctx.pairwise(counts, totals, metric); t2 = time.perf_counter() - t
+        m = None                                     # free the previous result outside the timed region (munmap of 7 GB)
+        t = time.perf_counter(); m = ctx.pairwise(counts, totals, metric); t2 = min(t2, time.perf_counter() - t)
     print("host-pointer ABI N=%d %s: po_count_profiles %.1f ms (H2D %d MB, D2H %d MB) | po_pairwise %.1f ms (D2H %.1f GB) -> %.3e pairs/s PCIe-inclusive"
           % (n, metric, t1 * 1e3, seq.nbytes >> 20, counts.nbytes >> 20, t2 * 1e3, m.nbytes / 1e9, pairs / t2), flush=True)
     del m

@@ -30,6 +30,7 @@ c, t = profiles("1111", 50002, ragged=True)
 ctx.pairwise(c, t, "JSD", out=out)                                # general JSD kernel
 ctx.pairwise(c, t, "BC", out=out)                                 # general BC kernel
 c, t = profiles("11011011", 50005)
-ctx.pairwise(c, t, "BC", out=out)                                 # C5
+ctx.pairwise(c, t, "BC", out=out)                                 # C5: thermometer planes on the matrix cores
+ctx.pairwise(c, t, "BC", out=out, pairdot=False)                  # C5 through the packed-byte SAD kernel
 torch.cuda.synchronize()
 print("done")
