@@ -25,7 +25,12 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kPerLane = 32;                       // window starts per lane
 constexpr int kTile = 64 * kPerLane;               // 2048 staged positions carrying a window start, per wave
-constexpr int kSpan = kTile - 16;                  // window starts per chunk (16 B alignment slack)
+constexpr int kSpan = kTile - 16;                  // window starts per pass (16 B alignment slack)
+constexpr int kPasses = 1;                         // passes per chunk.  A wave can walk several spans of one record before it
+                                                   // flushes its histogram (fewer global atomics on long records); measured at 8:
+                                                   // 115 vs 84 us on 2 kb contigs, 397 vs 349 us on a ragged 0.33 Gb assembly -
+                                                   // the serial passes expose the load latency that separate waves overlap.
+constexpr int kChunkSpan = kSpan * kPasses;
 constexpr int kStage = kTile + 64;                 // staged bytes per chunk (halo >= W-1 = 31, multiple of 16 B)
 constexpr uint32_t kMaxLdsBins = 16384;            // 64 KiB histogram; above that count in HBM directly
 
@@ -70,7 +75,7 @@ __device__ __forceinline__ uint32_t word_index(REG reg, const CountParams& P) {
 // record i is bytes [begins[i], ends[i]) of the sequence buffer (contiguous records: ends = begins + 1;
 // sliding windows: arbitrary, overlapping ranges)
 __device__ __forceinline__ uint32_t chunks_of(const uint64_t* begins, const uint64_t* ends, uint32_t i) {
-    return (uint32_t)((ends[i] - begins[i] + kSpan - 1) / kSpan);
+    return (uint32_t)((ends[i] - begins[i] + kChunkSpan - 1) / kChunkSpan);
 }
 
 // ---- chunks per record, exclusive scan -> chunk_start[n+1]: three small launches ----------------
@@ -156,11 +161,12 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     extern __shared__ __align__(16) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave >= waves_per_block) return;
-    const uint32_t per_wave_words = kStage / 4 + 64 + (LDS_HIST ? P.dim : 0);
+    const uint32_t per_wave_words = kStage / 4 + 64 + 4 + (LDS_HIST ? P.dim : 0);
     uint32_t* mine = smem + wave * per_wave_words;
     uint8_t* codes = reinterpret_cast<uint8_t*>(mine);            // [kStage]
     uint8_t* dtab = reinterpret_cast<uint8_t*>(mine + kStage / 4); // [256] byte -> digit
-    uint32_t* hist = mine + kStage / 4 + 64;                       // [dim] when LDS_HIST
+    uint32_t* mid_slot = mine + kStage / 4 + 64;                   // word of the self-mirrored junction window (symmetric mode)
+    uint32_t* hist = mine + kStage / 4 + 64 + 4;                   // [dim] when LDS_HIST
 
     const uint32_t b = blockIdx.x * waves_per_block + wave;
     const uint32_t nchunks = chunk_start[P.n_seqs];
@@ -181,10 +187,8 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     const uint32_t rec_chunks = chunk_start[rec + 1] - chunk_start[rec];
     const uint64_t off = begins[rec];
     const int64_t L = (int64_t)(ends[rec] - off);
-    const int64_t p_lo = (int64_t)chunk * kSpan;                   // window starts [p_lo, p_hi) are ours
-    const int64_t p_hi = min(p_lo + (int64_t)kSpan, L);
-    const uint64_t a0 = (off + (uint64_t)p_lo) & ~(uint64_t)15;    // 16 B aligned staging origin
-    const int64_t pos0 = (int64_t)a0 - (int64_t)off;               // record position of staged byte 0
+    const int64_t c_lo = (int64_t)chunk * kChunkSpan;              // window starts [c_lo, c_hi) are ours, kSpan per pass
+    const int64_t c_hi = min(c_lo + (int64_t)kChunkSpan, L);
 
     if (LDS_HIST)
         for (uint32_t d = lane * 4; d < P.dim; d += 256) *reinterpret_cast<uint4*>(hist + d) = make_uint4(0, 0, 0, 0);
@@ -198,6 +202,15 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
         for (int i = 0; i < 4; ++i) e |= base_digit(lane * 4 + i) << (8 * i);
         reinterpret_cast<uint32_t*>(dtab)[lane] = e;
     }
+    if (P.sym && lane == 0) *mid_slot = 0xFFFFFFFFu;
+    uint32_t mine_count = 0;
+    const uint32_t W = P.window;
+    constexpr bool want_plus = MODE != 1, want_minus = MODE != 0;
+    const uint32_t per_word = P.sym ? 2u : 1u;                      // a forward word also stands for its mirror window
+    for (int64_t p_lo = c_lo; p_lo < c_hi; p_lo += kSpan) {         // wave uniform; LDS is in order within a wave
+    const int64_t p_hi = min(p_lo + (int64_t)kSpan, L);
+    const uint64_t a0 = (off + (uint64_t)p_lo) & ~(uint64_t)15;    // 16 B aligned staging origin
+    const int64_t pos0 = (int64_t)a0 - (int64_t)off;               // record position of staged byte 0
     __builtin_amdgcn_wave_barrier();
     // all of the lane's 16-byte loads first (up to three HBM round trips in flight at once), then the decoding
     constexpr int kVecPerLane = (kStage / 16 + 63) / 64;
@@ -218,6 +231,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
             }
         }
     }
+    uint32_t sep_seen = 0;                                          // any byte that is not A/C/G/T among the staged ones
 #pragma unroll
     for (int it = 0; it < kVecPerLane; ++it) {
         const uint32_t v = lane + 64 * it;
@@ -230,6 +244,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
         for (int j = 0; j < 4; ++j)
             o[j] = (uint32_t)dtab[w[j] & 0xFFu] | ((uint32_t)dtab[(w[j] >> 8) & 0xFFu] << 8) |
                    ((uint32_t)dtab[(w[j] >> 16) & 0xFFu] << 16) | ((uint32_t)dtab[w[j] >> 24] << 24);
+        sep_seen |= (o[0] | o[1] | o[2] | o[3]) & 0x04040404u;
         if (nvalid < 16) {                                          // the vector holding the record end (and beyond): separators
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -242,10 +257,6 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     __builtin_amdgcn_wave_barrier();                               // LDS is in order within a wave
 
     // ---- slide: lane owns starts [32 lane, 32 lane + 32) ---------------------------------------------
-    const uint32_t W = P.window;
-    constexpr bool want_plus = MODE != 1, want_minus = MODE != 0;
-    const uint32_t per_word = P.sym ? 2u : 1u;                      // a forward word also stands for its mirror window
-    uint32_t mine_count = 0;
     {
         typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type reg_t;
         uint32_t cw[16];
@@ -259,8 +270,39 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
         const int64_t lo64 = p_lo - first, hi64 = p_hi - first;
         const int32_t s_lo = (int32_t)max(lo64, (int64_t)0), s_hi = (int32_t)min(hi64, (int64_t)kPerLane);
         reg_t fwd = 0, rev = 0;
-        uint32_t run = 0;
         const uint32_t top = 2 * W - 2;
+        // No byte other than A/C/G/T anywhere in the staged range (the usual case; decided per wave): every window that
+        // lies inside the record is a word, so the per-position run length and its tests go away - a start s counts iff
+        // s_lo <= s < s_hi' with s_hi' cut at the last start whose window ends inside the record.  Half the vector
+        // instructions of the general loop below (this kernel is bound by instruction issue, not by bytes).
+        if (!__any((int)(sep_seen != 0u))) {
+            const int64_t hi_valid = min(p_hi, L - (int64_t)W + 1) - first;
+            const int32_t s_hi2 = (int32_t)max((int64_t)s_lo, min(hi_valid, (int64_t)kPerLane));
+            const uint32_t span = (uint32_t)(s_hi2 - s_lo);              // starts of this lane that count
+            mine_count += span * ((want_plus ? per_word : 0u) + (want_minus ? 1u : 0u));
+#pragma unroll
+            for (int i = 0; i < kPerLane + PO_MAX_WINDOW - 1; ++i) {
+                if (i < (int)(kPerLane + W - 1)) {                      // uniform
+                    const uint32_t d = (cw[i >> 2] >> (8 * (i & 3))) & 3u;
+                    if (want_plus) fwd = (fwd << 2) | (reg_t)d;
+                    if (want_minus) rev = (rev >> 2) | ((reg_t)(d ^ 1u) << top);
+                    const int s = i - (int)(W - 1);                     // window start index of this lane (uniform)
+                    if (s >= 0 && (uint32_t)(s - s_lo) < span) {
+                        if (want_plus) {
+                            const uint32_t idx = word_index<reg_t, RUNS>(fwd, P);
+                            if (LDS_HIST) atomicAdd(&hist[idx], 1u);
+                            else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
+                        }
+                        if (want_minus) {
+                            const uint32_t idx = word_index<reg_t, RUNS>(rev, P);
+                            if (LDS_HIST) atomicAdd(&hist[idx], 1u);
+                            else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
+                        }
+                    }
+                }
+            }
+        } else {
+        uint32_t run = 0;
 #pragma unroll
         for (int i = 0; i < kPerLane + PO_MAX_WINDOW - 1; ++i) {
             if (i < (int)(kPerLane + W - 1)) {                      // uniform
@@ -287,15 +329,14 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                 }
             }
         }
+        }
     }
 
     // ---- junction words of seq + revcomp(seq) (-s both), by the chunk holding the record end ----
     // Symmetric mode: the W-1 junction windows are mirror images of each other (start p <-> 2L - W - p), so only the
     // first of each pair is added (the write-out doubles it); for even W the middle window is its own mirror and
     // spells a self-paired word, which is added once, after the doubling (mid_word).
-    uint32_t* mid_slot = reinterpret_cast<uint32_t*>(dtab);         // the decode table is no longer needed
-    if (P.sym && lane == 0) *mid_slot = 0xFFFFFFFFu;
-    if (P.strand == PO_STRAND_BOTH && chunk == rec_chunks - 1 && lane < W - 1) {
+    if (P.strand == PO_STRAND_BOTH && p_hi == L && lane < W - 1) {    // the pass that holds the record end
         const int64_t p = L - (int64_t)W + 1 + (int64_t)lane;       // start in the 2L-long virtual string
         const bool first_of_pair = 2 * p < 2 * L - (int64_t)W, middle = 2 * p == 2 * L - (int64_t)W;
         if (p >= 0 && p < L && p + (int64_t)W <= 2 * L && (!P.sym || first_of_pair || middle)) {
@@ -323,6 +364,8 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
             }
         }
     }
+
+    }   // passes
 
     // ---- totals: wave reduce, one store / atomic per chunk ----------------------------------------
     for (int o = 32; o > 0; o >>= 1) mine_count += __shfl_down(mine_count, o, 64);
@@ -361,7 +404,7 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
                     uint64_t* d_totals) {
     if (n_seqs == 0) return PO_OK;
     if (n_seqs >= (1ull << 31)) { po_set_error("too many records (%llu)", (unsigned long long)n_seqs); return PO_EUNSUPPORTED; }
-    const uint64_t max_chunks = sum_lengths / kSpan + n_seqs;
+    const uint64_t max_chunks = sum_lengths / kChunkSpan + n_seqs;
     if (max_chunks >= (1ull << 31)) { po_set_error("input too large for one launch"); return PO_EUNSUPPORTED; }
 
     const uint32_t nb = (uint32_t)((n_seqs + 1023) / 1024);
@@ -398,7 +441,7 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     P.total_bytes = total_bytes;
 
     const bool lds_hist = pat.dim <= kMaxLdsBins;
-    const size_t per_wave = kStage + 256 + (lds_hist ? (size_t)pat.dim * 4 : 0);
+    const size_t per_wave = kStage + 256 + 16 + (lds_hist ? (size_t)pat.dim * 4 : 0);
     uint32_t wpb = (uint32_t)((80u << 10) / per_wave);                // waves per workgroup within 80 KiB of LDS
     wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
     const size_t shmem = per_wave * wpb;

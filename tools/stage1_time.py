@@ -1,0 +1,40 @@
+"""Stage-1 wall time (3 calls, best) on the C2 assembly for a few patterns / strands, and on a ragged assembly."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, '.')
+import phyloligo_amd as pa
+from phyloligo_amd import synthetic
+ctx = pa.Context(0)
+seq, off = synthetic.contig_bytes(50000, 2000, seed=50001)
+dseq = torch.from_numpy(seq).cuda(); doff = torch.from_numpy(off.astype(np.int64)).cuda()
+
+
+def best(dseq, doff, pattern, strand, reps=5):
+    b = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        c, tt = ctx.count_profiles(dseq, doff, pattern, strand)
+        torch.cuda.synchronize(); b = min(b, time.perf_counter() - t)
+    return b, c
+
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+configs = (("1111", "both"), ("1111", "plus"), ("11011011", "both"), ("1101", "both"), ("111111", "both"))
+if which not in ("all", "ragged"):
+    configs = tuple(c for c in configs if "%s_%s" % c == which)
+if which == "ragged":
+    configs = ()
+for pattern, strand in configs:
+    t, c = best(dseq, doff, pattern, strand)
+    nbytes = seq.size + c.numel() * 4 + 50000 * 8
+    print("C2 %-9s %-5s %7.1f us  %5.2f TB/s algorithmic (%.0f MB)" % (pattern, strand, t * 1e6, nbytes / t / 1e12, nbytes / 1e6), flush=True)
+if which not in ("all", "ragged"):
+    sys.exit(0)
+rng = np.random.default_rng(2024)
+n = 50000
+lens = np.clip(np.exp(rng.normal(np.log(4000), 1.0, size=n)), 1000, 200000).astype(np.int64)
+o2 = np.zeros(n + 1, dtype=np.int64); o2[1:] = np.cumsum(lens)
+s2 = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")[torch.randint(0, 4, (int(o2[-1]),), device="cuda")]
+t, c = best(s2, torch.from_numpy(o2).cuda(), "1111", "both")
+nbytes = int(o2[-1]) + c.numel() * 4 + n * 8
+print("ragged 0.33 Gb 1111 both %7.1f us  %5.2f TB/s algorithmic" % (t * 1e6, nbytes / t / 1e12), flush=True)
