@@ -412,11 +412,11 @@ static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
     } else {
         rc = po_buf_reserve(ctx, &ctx->ws_aux, n * (uint64_t)dim * sizeof(uint32_t));
         if (rc) return rc;
-        if (po_kt_pairdot_supported(dim)) {   // uint8 ranks + the materialised pair-sign operand
-            rc = po_buf_reserve(ctx, &ctx->ws_freq, po_kt_pairdot_rank_bytes(n, dim));
-            if (rc) return rc;
-        } else if (po_kt_panel_supported(dim)) {   // uint16 ranks of the panel kernel
-            rc = po_buf_reserve(ctx, &ctx->ws_freq, po_kt_panel_workspace(n, dim));
+        size_t kt_ws = 0;
+        if (po_kt_pairdot_supported(dim)) kt_ws = po_kt_pairdot_rank_bytes(n, dim);          // ranks of the pair-dot path
+        if (po_kt_panel_supported(dim) && po_kt_panel_workspace(n, dim) > kt_ws) kt_ws = po_kt_panel_workspace(n, dim);
+        if (kt_ws) {
+            rc = po_buf_reserve(ctx, &ctx->ws_freq, kt_ws);
             if (rc) return rc;
         }
     }
@@ -561,9 +561,10 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     po_kt_panel_plan kt_pplan;
     memset(&kt_plan, 0, sizeof(kt_plan));
     memset(&kt_pplan, 0, sizeof(kt_pplan));
-    const bool kt_mfma = metric == PO_KT && po_kt_pairdot_supported(dim) && !(flags & (PO_FLAG_NO_TABLE_PATH | PO_FLAG_NO_PAIRDOT));
-    const bool kt_panel = metric == PO_KT && !kt_mfma && po_kt_panel_supported(dim) && !(flags & PO_FLAG_NO_TABLE_PATH);
-    if (kt_mfma || kt_panel) {
+    bool kt_mfma = metric == PO_KT && po_kt_pairdot_supported(dim) && !(flags & (PO_FLAG_NO_TABLE_PATH | PO_FLAG_NO_PAIRDOT));
+    const bool kt_panel_ok = metric == PO_KT && po_kt_panel_supported(dim) && !(flags & PO_FLAG_NO_TABLE_PATH);
+    bool kt_panel = false;
+    if (kt_mfma || kt_panel_ok) {
         // strand-symmetric records: Kendall's S over one word per reverse-complement orbit, weighted (po_fold.hip)
         const uint32_t selfs = po_fold_selfs(dim);
         const uint32_t* fold_src = nullptr;
@@ -576,10 +577,15 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
             if (folded) fold_src = static_cast<const uint32_t*>(ctx->ws_fold_src.p);
         }
         const uint32_t n_pairs = fold_src ? (dim - selfs) / 2 : 0;
-        rc = kt_mfma ? po_launch_kt_pairdot_prep(ctx, lessrank, n, dim, npad, fold_src, selfs, n_pairs,
-                                                 (flags & PO_FLAG_PAIRDOT_I8) ? 0 : 1, &kt_plan)
-                     : po_launch_kt_panel_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, fold_src, fold_len, selfs, n_pairs,
-                                               &kt_pplan);
+        const int want_fp4 = (flags & PO_FLAG_PAIRDOT_I8) ? 0 : 1;
+        // the materialised operand must stay within bounds (it grows with D^2: 1 MB per record at folded k = 6)
+        if (kt_mfma && po_kt_pairdot_operand_bytes(n, dim, fold_src ? selfs + n_pairs : dim, selfs, fold_src != nullptr, want_fp4) >
+                           PO_PAIRDOT_MAX_OPERAND)
+            kt_mfma = false;
+        kt_panel = !kt_mfma && kt_panel_ok;
+        if (kt_panel && fold_src && !po_kt_panel_fold_supported(dim, selfs)) { fold_src = nullptr; folded = false; }
+        if (kt_mfma) rc = po_launch_kt_pairdot_prep(ctx, lessrank, n, dim, npad, fold_src, selfs, n_pairs, want_fp4, &kt_plan);
+        else if (kt_panel) rc = po_launch_kt_panel_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, fold_src, fold_len, selfs, n_pairs, &kt_pplan);
         if (rc) return rc;
     }
     if (metric == PO_EUCL || (metric == PO_SC && !sc_i8)) {

@@ -205,7 +205,8 @@ struct po_pairdot_plan {
 };
 bool po_kt_pairdot_supported(uint32_t dim);
 size_t po_kt_pairdot_rank_bytes(uint64_t n, uint32_t dim);
-size_t po_kt_pairdot_operand_bytes(uint64_t n, uint32_t dim, int fmt_fp4);
+size_t po_kt_pairdot_operand_bytes(uint64_t n, uint32_t dim, uint32_t words, uint32_t n_selfs, bool folded, int fmt_fp4);
+#define PO_PAIRDOT_MAX_OPERAND (24ull << 30)   // the materialised operand lives in the context's workspace until it is destroyed
 int po_launch_kt_pairdot_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, uint64_t npad,
                               const uint32_t* fold_src, uint32_t n_selfs, uint32_t n_pairs, int fmt_fp4,
                               po_pairdot_plan* plan);

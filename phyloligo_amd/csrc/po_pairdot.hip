@@ -267,6 +267,49 @@ __global__ __launch_bounds__(256) void kt_expand_kernel(const uint8_t* __restric
     }
 }
 
+// ---- word spaces above 256 words: uint16 ranks, kept transposed in HBM (an LDS copy of 64 rank rows no longer fits) ----
+// rankT[c][rec] = lessrank[rec][src ? src[c] : c]  (uint16; zero beyond the words / records)
+__global__ __launch_bounds__(256) void rank16t_kernel(const uint32_t* __restrict__ lessrank, uint64_t n, uint32_t dim,
+                                                      const uint32_t* __restrict__ src, uint32_t words, uint64_t op_n,
+                                                      uint16_t* __restrict__ rankT) {
+    const uint64_t total = (uint64_t)words * op_n;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t c = i / op_n, r = i - c * op_n;
+        const uint32_t w = src ? src[c] : (uint32_t)c;                 // 0xFFFFFFFF: padding column
+        rankT[i] = (r < n && w < dim) ? (uint16_t)lessrank[r * dim + w] : (uint16_t)0;
+    }
+}
+
+// thread = (record, chunk).  The pair table walks q for a fixed p, so x_p stays in a register for most elements.
+template <int FMT>
+__global__ __launch_bounds__(256) void kt_expand16_kernel(const uint16_t* __restrict__ rankT, const uint32_t* __restrict__ pq,
+                                                          uint32_t n_chunks, uint8_t* __restrict__ op, uint64_t op_n) {
+    constexpr int EPC = elems_per_chunk(FMT);
+    const uint32_t t = threadIdx.x, lane = t & 63;
+    const uint64_t rec = (uint64_t)blockIdx.x * 64 + lane;             // < op_n: the grid covers the padded records
+    const uint32_t w0 = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (t >> 6));
+    for (uint32_t ch = w0; ch < n_chunks; ch += gridDim.y * 4) {
+        const uint32_t* codes = pq + (size_t)ch * EPC;      // wave uniform
+        uint32_t word[4] = {0, 0, 0, 0};
+        uint32_t cached_p = 0xFFFFFFFFu;
+        int a = 0;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const uint32_t code = codes[e];
+            const uint32_t p = code & 0xFFFFu, q = code >> 16;
+            if (p != cached_p) {                             // uniform branch
+                cached_p = p;
+                a = rankT[(uint64_t)p * op_n + rec];
+            }
+            const int b = rankT[(uint64_t)q * op_n + rec];
+            const int s = (b > a) - (b < a);
+            if (FMT == FMT_I8) word[e >> 2] |= ((uint32_t)s & 0xFFu) << (8 * (e & 3));
+            else word[e >> 3] |= (s > 0 ? 0x2u : (s < 0 ? 0xAu : 0x0u)) << (4 * (e & 7));
+        }
+        *reinterpret_cast<uint4*>(op + ((uint64_t)ch * op_n + rec) * 16) = make_uint4(word[0], word[1], word[2], word[3]);
+    }
+}
+
 template <int FMT, int EPI>
 int launch_tiles(po_ctx* ctx, const po_tile_args& a, const uint8_t* op, uint64_t op_n, uint32_t n_stages, uint32_t dbl1,
                  uint32_t dbl2, const pd_epilogue& E, uint64_t* tiles) {
@@ -292,7 +335,7 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const uint8_t* op, uint64_t
 }  // namespace
 
 // ---- Kendall ---------------------------------------------------------------------------------------------------
-bool po_kt_pairdot_supported(uint32_t dim) { return dim >= 2 && dim <= 256; }          // uint8 ranks
+bool po_kt_pairdot_supported(uint32_t dim) { return dim >= 2 && dim <= 16384; }      // uint8 ranks up to 256 words, uint16 above
 
 static uint32_t kt_classes(uint32_t words, uint32_t n_selfs, bool folded, uint64_t cnt[3]) {
     if (!folded) { cnt[0] = (uint64_t)words * (words - 1) / 2; cnt[1] = cnt[2] = 0; return 1; }
@@ -303,14 +346,22 @@ static uint32_t kt_classes(uint32_t words, uint32_t n_selfs, bool folded, uint64
     return 3;
 }
 
+// float32 sums of FP4 products are exact below 2^24: |S| <= D (D - 1) / 2 decides the operand format
+static bool kt_fp4_exact(uint32_t dim) { return (uint64_t)dim * (dim - 1) / 2 < (1ull << 24); }
+
+// rank buffer: uint8 [npad][round16(D)] (D <= 256) or uint16 transposed [D][round256(n)]
 size_t po_kt_pairdot_rank_bytes(uint64_t n, uint32_t dim) {
-    return po_round_up(n ? n : 1, 128) * po_round_up(dim, 16) + 256;
+    if (dim <= 256) return po_round_up(n ? n : 1, 128) * po_round_up(dim, 16) + 256;
+    return (size_t)dim * po_round_up(n ? n : 1, TE) * sizeof(uint16_t) + 256;
 }
 
-// operand bytes for n records (largest case: unfolded, int8)
-size_t po_kt_pairdot_operand_bytes(uint64_t n, uint32_t dim, int fmt_fp4) {
-    const uint64_t epc = fmt_fp4 ? 32 : 16, per_stage = epc * SCH;
-    const uint64_t k = po_round_up((uint64_t)dim * (dim - 1) / 2, per_stage) + 2 * per_stage;
+// bytes of the materialised operand for n records of `words` kept words (n_selfs of them self-paired when folded)
+size_t po_kt_pairdot_operand_bytes(uint64_t n, uint32_t dim, uint32_t words, uint32_t n_selfs, bool folded, int fmt_fp4) {
+    const uint64_t epc = (fmt_fp4 && kt_fp4_exact(dim)) ? 32 : 16, per_stage = epc * SCH;
+    uint64_t cnt[3], k = 0;
+    const uint32_t nc = kt_classes(words, n_selfs, folded, cnt);
+    for (uint32_t c = 0; c < nc; ++c) k += po_round_up(cnt[c], per_stage);
+    if (k == 0) k = per_stage;
     return (k / epc) * po_round_up(n ? n : 1, TE) * 16 + 256;
 }
 
@@ -321,6 +372,7 @@ int po_launch_kt_pairdot_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t 
     const bool folded = fold_src != nullptr;
     const uint32_t words = folded ? n_selfs + n_pairs : dim;
     const uint32_t row_bytes = folded ? (uint32_t)po_round_up(words, 16) : dim;
+    if (!kt_fp4_exact(dim)) fmt_fp4 = 0;                   // k = 7: sums up to 1.3e8 need the int32 accumulators
     const uint32_t epc = fmt_fp4 ? 32u : 16u, per_stage = epc * SCH;
     uint64_t cnt[3];
     const uint32_t n_classes = kt_classes(words, n_selfs, folded, cnt);
@@ -356,16 +408,28 @@ int po_launch_kt_pairdot_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t 
     const uint32_t n_chunks = (uint32_t)(kpad / epc);
     rc = po_buf_reserve(ctx, &ctx->ws_pairdot, (size_t)n_chunks * op_n * 16);
     if (rc) return rc;
-    uint8_t* rank8 = static_cast<uint8_t*>(ctx->ws_freq.p);            // reserved by the caller (po_kt_pairdot_rank_bytes)
-    hipLaunchKernelGGL(rank8_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_lessrank, n, dim, npad, fold_src, row_bytes, rank8);
-    PO_CHECK_LAUNCH("rank8_kernel");
-    const dim3 grid((uint32_t)(op_n / 64), 8);
-    const size_t shmem = (size_t)row_bytes * 64;
     const uint32_t* pq = static_cast<const uint32_t*>(ctx->ws_pq.p);
     uint8_t* op = static_cast<uint8_t*>(ctx->ws_pairdot.p);
-    if (fmt_fp4) hipLaunchKernelGGL(kt_expand_kernel<FMT_FP4>, grid, dim3(256), shmem, ctx->stream, rank8, row_bytes, npad, pq, n_chunks, op, op_n);
-    else hipLaunchKernelGGL(kt_expand_kernel<FMT_I8>, grid, dim3(256), shmem, ctx->stream, rank8, row_bytes, npad, pq, n_chunks, op, op_n);
-    PO_CHECK_LAUNCH("kt_expand_kernel");
+    if (dim <= 256) {
+        uint8_t* rank8 = static_cast<uint8_t*>(ctx->ws_freq.p);        // reserved by the caller (po_kt_pairdot_rank_bytes)
+        hipLaunchKernelGGL(rank8_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_lessrank, n, dim, npad, fold_src, row_bytes, rank8);
+        PO_CHECK_LAUNCH("rank8_kernel");
+        const dim3 grid((uint32_t)(op_n / 64), 8);
+        const size_t shmem = (size_t)row_bytes * 64;
+        if (fmt_fp4) hipLaunchKernelGGL(kt_expand_kernel<FMT_FP4>, grid, dim3(256), shmem, ctx->stream, rank8, row_bytes, npad, pq, n_chunks, op, op_n);
+        else hipLaunchKernelGGL(kt_expand_kernel<FMT_I8>, grid, dim3(256), shmem, ctx->stream, rank8, row_bytes, npad, pq, n_chunks, op, op_n);
+        PO_CHECK_LAUNCH("kt_expand_kernel");
+    } else {
+        uint16_t* rankT = static_cast<uint16_t*>(ctx->ws_freq.p);
+        hipLaunchKernelGGL(rank16t_kernel, dim3(2048), dim3(256), 0, ctx->stream, d_lessrank, n, dim, fold_src, words, op_n, rankT);
+        PO_CHECK_LAUNCH("rank16t_kernel");
+        uint32_t gy = (n_chunks + 255) / 256;                          // ~64 chunks per wave
+        gy = gy < 1 ? 1 : (gy > 4096 ? 4096 : gy);
+        const dim3 grid((uint32_t)(op_n / 64), gy);
+        if (fmt_fp4) hipLaunchKernelGGL(kt_expand16_kernel<FMT_FP4>, grid, dim3(256), 0, ctx->stream, rankT, pq, n_chunks, op, op_n);
+        else hipLaunchKernelGGL(kt_expand16_kernel<FMT_I8>, grid, dim3(256), 0, ctx->stream, rankT, pq, n_chunks, op, op_n);
+        PO_CHECK_LAUNCH("kt_expand16_kernel");
+    }
     plan->fmt_fp4 = fmt_fp4 ? 1 : 0;
     plan->n_stages = (uint32_t)(kpad / per_stage);
     plan->op_n = op_n;

@@ -109,3 +109,25 @@ def test_bc_thermometer_through_blocks(ctx):
         slabs.append(slab)
         mirrors.append(m)
     assert torch.equal(assemble_virtual(plan, slabs, mirrors), full)
+
+
+@pytest.mark.parametrize("pattern,strand,n", [("11111", "both", 300), ("11111", "plus", 200), ("110111", "both", 130),
+                                              ("11011011", "both", 140)])
+def test_kt_pairdot_large_word_spaces(ctx, pattern, strand, n):
+    """Kendall above 256 words (k = 5, 6): uint16 ranks kept transposed in HBM, the pair-sign operand materialised
+    once (up to 1 MB per record), against the panel kernel (pairdot=False) and the O(D^2) vector kernel - S is an
+    integer, so all three agree bit for bit; FP4 and int8 operands too."""
+    rng = np.random.default_rng(n)
+    contigs = [c[:int(rng.integers(600, 2000))] for c in fixed_length(n, 2000, seed=n + 1)]
+    contigs[5] = contigs[9]
+    seq, off = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, off, pattern, strand)
+    fast, st = ctx.pairwise(counts, totals, "KT", want_stats=True)
+    panel, st_p = ctx.pairwise(counts, totals, "KT", want_stats=True, pairdot=False)
+    assert st["kernel_id"] == 8 and st_p["kernel_id"] == 8
+    assert np.array_equal(fast, panel)
+    assert np.array_equal(fast, ctx.pairwise(counts, totals, "KT", pairdot_i8=True))
+    if counts.shape[1] <= 1024:
+        assert np.array_equal(fast, ctx.pairwise(counts, totals, "KT", table_path=False))
+    assert np.array_equal(fast, fast.T) and fast[5, 9] == 1.0 and np.all(np.diag(fast) == 1.0)
+    np.testing.assert_array_equal(ctx.pairwise(counts, totals, "KT", row_begin=7, row_end=101), fast[7:101])
