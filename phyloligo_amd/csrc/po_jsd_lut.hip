@@ -144,17 +144,17 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void jsd_lut_tile_ker
         const uint32_t* sB = stage + cur * kStageWords + KC * TM + tx * 2;
 #pragma unroll 2
         for (int k = 0; k < KC; ++k) {
-            uint32_t a[RPT];
+            uint32_t a[RPT];                               // table base (this lane's copy) folded into the row side: RPT adds, not 8
 #pragma unroll
             for (int q = 0; q < RPT / 4; ++q) {
                 const uint4 av = *reinterpret_cast<const uint4*>(sA + k * TM + 4 * q);
-                a[4 * q] = av.x; a[4 * q + 1] = av.y; a[4 * q + 2] = av.z; a[4 * q + 3] = av.w;
+                a[4 * q] = av.x + tcopy; a[4 * q + 1] = av.y + tcopy; a[4 * q + 2] = av.z + tcopy; a[4 * q + 3] = av.w + tcopy;
             }
-            uint32_t b[8];                                 // columns 32*q + 2*tx + {0,1}, table base folded in
+            uint32_t b[8];                                 // columns 32*q + 2*tx + {0,1}
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint2 bv = *reinterpret_cast<const uint2*>(sB + k * TN + 32 * q);
-                b[2 * q] = bv.x + tcopy; b[2 * q + 1] = bv.y + tcopy;
+                b[2 * q] = bv.x; b[2 * q + 1] = bv.y;
             }
             // the 8 lookups of register-block row ia+1 are in flight while row ia is accumulated
             double tv[2][8];
