@@ -108,6 +108,9 @@ def _write_raw_f32(out_file, n, rows, writers=8):
         os.close(fd)
 
 
+_SINGLE_CALL_BYTES = 4 << 30      # larger float64 matrices are computed and copied in row blocks
+
+
 def _row_chunk(n, itemsize, budget=1 << 30):
     return max(128, (budget // max(1, n * itemsize)) // 128 * 128)
 
@@ -148,7 +151,7 @@ def compute_distances(mthdrun, large, frequencies, freq_name, out_file, dist, th
     if large == "memmap":
         _write_raw_f32(out_file, n, rows)
         return None
-    if n * n * 8 <= (4 << 30):
+    if n * n * 8 <= _SINGLE_CALL_BYTES:
         return rows(0, n, "float64", True)
     res = np.empty((n, n), dtype=np.float64)
     step = _row_chunk(n, 8)

@@ -30,3 +30,37 @@ def test_bench_json_contract():
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert r["value"] > 100 * cb["value"]
+    assert cb["cores"] <= cb["host_cpus_visible"] and cb["c1_full"]["metric_calls"] == 1000000
+    assert r["config"]["env_knobs"] == {k: v for k, v in os.environ.items() if k.startswith("PO_")}
+    gen = r["config"]["jsd_general_kernel_only"]
+    assert gen["roofline"]["frac"] > 0 and gen["pairs_per_s"] < r["value"] * 1.5
+    assert r["scaling"] == "weak" and "seed 50001" in r["config"]["workload"]
+
+
+def test_bench_multi_rank_path_rehearsal():
+    """The N > 1 code path (process group, one all-gather of the counts, tournament work lists, per-rank kernel times)
+    with two ranks sharing this one GPU over gloo: numbers are meaningless, the record's shape is what is checked.
+    The driver's real run is one rank per GPU over RCCL and defaults to BASELINE config 4 (200 000 contigs)."""
+    env = dict(os.environ, PO_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--contigs", "4096", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and "seed 200001" in r["config"]["workload"]
+    mg = r["config"]["multi_gpu"]
+    assert mg["ranks_seen"] == 2 and len(mg["kernel_ms_per_rank"]) == 2 and mg["allgather_ms"] > 0
+    assert mg["kernel_ms_min"] <= mg["kernel_ms_max"] and mg["allgather_bytes"] == 4096 * 256 * 4 + 4096 * 8
+    assert r["config"]["env_knobs"].get("PO_BENCH_REHEARSAL") == "1"
+    assert abs(r["value"] - r["config"]["pairs"] / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+
+
+def test_bench_default_workloads_are_the_baseline_configs():
+    """bench.py --gpus 1 = BASELINE config 2, --gpus N > 1 = BASELINE config 4 (read from the source: running 200 000
+    contigs needs more than one GPU)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'n, cfg_name, seed = 50000, "BASELINE config 2", synthetic.SEEDS["C2"]' in src
+    assert 'n, cfg_name, seed = 200000, "BASELINE config 4", synthetic.SEEDS["C4"]' in src

@@ -142,3 +142,37 @@ def test_out_buffer_is_validated():
         ok = np.full((40, 48), -1.0)
         ctx.pairwise(counts, totals, "Eucl", out=ok)
         assert (ok[:, 40:] == -1.0).all() and (ok[:, :40] >= 0).all()
+
+
+def test_row_block_paths_of_the_dispatcher(fasta, tmp_path, monkeypatch):
+    """Matrices above 4 GB are computed and copied in row blocks, and the raw float32 container is written block by
+    block from two host buffers: force both paths at a small size and compare with the one-call result."""
+    from phyloligo_amd import phyloligo as P
+    path, g = fasta
+    freq, _ = P.compute_frequencies("joblib", "None", path, "1111", "both", 250, 4, ".")
+    whole = P.compute_distances("joblib", "None", freq, None, "unused", "JSD", 4, 250, ".")
+    monkeypatch.setattr(P, "_SINGLE_CALL_BYTES", 1024)
+    monkeypatch.setattr(P, "_row_chunk", lambda n, itemsize, budget=0: 7)          # 7-row blocks: ragged last block
+    blocks = P.compute_distances("joblib", "None", freq, None, "unused", "JSD", 4, 250, ".")
+    np.testing.assert_allclose(blocks, whole, rtol=1e-12, atol=1e-15)
+    out = tmp_path / "blocks.f32"
+    assert P.compute_distances("joblib", "memmap", freq, None, str(out), "JSD", 4, 250, ".") is None
+    raw = np.fromfile(out, dtype=np.float32).reshape(whole.shape)
+    assert np.array_equal(raw, whole.astype(np.float32)) or np.allclose(raw, whole, rtol=1e-6, atol=1e-7)
+
+
+def test_bc_from_frequencies_takes_the_thermometer_path():
+    """The reference's dispatcher hands over float64 frequencies: count2freq output is traced back to the integer
+    profiles on the device and then takes the same kernels as the count entry point (here: BC on thermometer planes)."""
+    import phyloligo_amd as pa
+    rng = np.random.default_rng(3)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    contigs = [acgt[rng.integers(0, 4, size=1500)].tobytes() for _ in range(300)]
+    seq = np.frombuffer(b"".join(contigs), dtype=np.uint8).copy()
+    off = np.arange(301, dtype=np.uint64) * np.uint64(1500)
+    with pa.Context(0) as ctx:
+        counts, totals = ctx.count_profiles(seq, off, "11011011", "both")
+        a, st_a = ctx.pairwise(counts, totals, "BC", want_stats=True)
+        b, st_b = ctx.pairwise_freq(ctx.frequencies(counts, totals), "BC", want_stats=True)
+        assert st_a["kernel_id"] == 9 and st_b["kernel_id"] == 9
+        assert np.array_equal(a, b)
