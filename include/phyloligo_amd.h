@@ -168,6 +168,10 @@ int po_profile_distances(po_ctx* ctx, const uint32_t* counts, const uint64_t* to
                          const double* proto, int metric, double* out);
 int po_profile_distances_dev(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
                              uint32_t dim, const double* d_proto, int metric, double* d_out);
+/* Occurrences of one byte value in every range - the numerator of Kount.py's N gate, seq.count("N") / len(seq)
+ * (bin/Kount.py:295), for the same windows, without a pass over the genome on the host.  Device pointers.       */
+int po_count_byte_ranges_dev(po_ctx* ctx, const uint8_t* d_seq, uint64_t total_bytes, const uint64_t* d_begins,
+                             const uint64_t* d_ends, uint64_t n_ranges, int byte, uint64_t* d_out);
 
 /* ---- stage 2: pairwise matrix ----------------------------------------------------------- *
  * Replaces compute_distances_joblib (bin/phyloligo.py:364-392) = sklearn pairwise_distances

@@ -65,6 +65,7 @@ SIGNATURES = {
     "po_count_profiles_ranges_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _u64, _cp, _int, _vp, _vp]),
     "po_profile_distances": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _int, _vp]),
     "po_profile_distances_dev": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _int, _vp]),
+    "po_count_byte_ranges_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _u64, _int, _vp]),
     "po_frequencies": (_int, [_vp, _vp, _vp, _u64, _u32, _vp]),
     "po_frequencies_dev": (_int, [_vp, _vp, _vp, _u64, _u32, _vp]),
     "po_pairwise": (_int, [_vp, _vp, _vp, _u64, _u32, _int, _u64, _u64, _int, _vp, _u64, _u32, _c.POINTER(PoStats)]),

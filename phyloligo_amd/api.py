@@ -109,11 +109,25 @@ class Context:
 
     def count_profiles_ranges(self, seq, begins, ends, pattern="1111", strand="both"):
         """Profiles of arbitrary (overlapping) byte ranges [begins[i], ends[i]) of one sequence buffer --
-        Kount.py's sliding windows.  numpy in -> numpy out."""
+        Kount.py's sliding windows.  numpy in -> numpy out; torch CUDA tensors in -> torch CUDA tensors out."""
         pat = normalise_pattern(pattern)
         _, _, dim = pattern_info(pat)
         if strand not in STRANDS:
             raise _lib.PhyloligoError(_lib.PO_EINVAL, "strand must be one of both/plus/minus (got %r)" % (strand,))
+        if _is_torch(seq):
+            import torch
+            self._check_device(seq, begins, ends)
+            assert seq.dtype == torch.uint8 and seq.is_contiguous()
+            assert begins.dtype == torch.int64 and ends.dtype == torch.int64 and begins.is_contiguous() and ends.is_contiguous()
+            n = begins.numel()
+            counts = torch.empty((n, dim), dtype=torch.int32, device=seq.device)
+            totals = torch.empty((n,), dtype=torch.int64, device=seq.device)
+            sum_lengths = int((ends - begins).sum().item()) if n else 0
+            self._use_torch_stream()
+            check(self._lib.po_count_profiles_ranges_dev(self._h, seq.data_ptr(), seq.numel(), begins.data_ptr(), ends.data_ptr(), n,
+                                                         sum_lengths, pat.encode(), STRANDS[strand], counts.data_ptr(),
+                                                         totals.data_ptr()))
+            return counts, totals
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         begins = np.ascontiguousarray(begins, dtype=np.uint64)
         ends = np.ascontiguousarray(ends, dtype=np.uint64)
@@ -124,11 +138,39 @@ class Context:
                                                  pat.encode(), STRANDS[strand], _np_ptr(counts), _np_ptr(totals)))
         return counts, totals
 
+    def _check_device(self, *tensors):
+        for t in tensors:
+            if t.device.type != "cuda" or t.device.index != self.device:
+                raise _lib.PhyloligoError(_lib.PO_EINVAL, "tensor is on %s, this context drives cuda:%d" % (t.device, self.device))
+
+    def count_byte_ranges(self, seq, begins, ends, byte):
+        """Occurrences of one byte value in every range (device tensors): the numerator of Kount.py's N gate."""
+        import torch
+        self._check_device(seq, begins, ends)
+        assert seq.dtype == torch.uint8 and begins.dtype == torch.int64 and ends.dtype == torch.int64
+        out = torch.empty((begins.numel(),), dtype=torch.int64, device=seq.device)
+        self._use_torch_stream()
+        check(self._lib.po_count_byte_ranges_dev(self._h, seq.data_ptr(), seq.numel(), begins.data_ptr(), ends.data_ptr(),
+                                                 begins.numel(), int(byte), out.data_ptr()))
+        return out
+
     def profile_distances(self, counts, totals, proto, metric="JSD"):
         """Distance of every profile to ONE prototype frequency vector (Kount.py's JSD / KL / Eucl, unscaled)."""
         code = {"Eucl": 0, "JSD": 1, "KL": _lib.PO_KL}.get(metric)
         if code is None:
             raise _lib.PhyloligoError(_lib.PO_EINVAL, "metric must be JSD, KL or Eucl (got %r)" % (metric,))
+        if _is_torch(counts):
+            import torch
+            self._check_device(counts, totals)
+            n, dim = counts.shape
+            assert counts.dtype == torch.int32 and totals.dtype == torch.int64 and counts.is_contiguous()
+            d_proto = proto if _is_torch(proto) else torch.from_numpy(np.ascontiguousarray(proto, dtype=np.float64)).to(counts.device)
+            assert d_proto.dtype == torch.float64 and d_proto.numel() == dim
+            out = torch.empty((n,), dtype=torch.float64, device=counts.device)
+            self._use_torch_stream()
+            check(self._lib.po_profile_distances_dev(self._h, counts.data_ptr(), totals.data_ptr(), n, dim, d_proto.data_ptr(),
+                                                     code, out.data_ptr()))
+            return out
         counts = np.ascontiguousarray(counts, dtype=np.uint32)
         totals = np.ascontiguousarray(totals, dtype=np.uint64)
         proto = np.ascontiguousarray(proto, dtype=np.float64)

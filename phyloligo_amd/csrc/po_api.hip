@@ -362,6 +362,18 @@ extern "C" int po_count_profiles_ranges(po_ctx* ctx, const uint8_t* seq, uint64_
     return PO_OK;
 }
 
+extern "C" int po_count_byte_ranges_dev(po_ctx* ctx, const uint8_t* d_seq, uint64_t total_bytes, const uint64_t* d_begins,
+                                        const uint64_t* d_ends, uint64_t n_ranges, int byte, uint64_t* d_out) {
+    PO_REQUIRE(ctx != nullptr, "po_count_byte_ranges_dev: ctx is NULL");
+    if (n_ranges == 0) return PO_OK;
+    PO_REQUIRE(d_begins && d_ends && d_out, "po_count_byte_ranges_dev: NULL buffer");
+    PO_REQUIRE(d_seq != nullptr || total_bytes == 0, "po_count_byte_ranges_dev: NULL sequence buffer");
+    PO_REQUIRE((reinterpret_cast<uintptr_t>(d_seq) & 15u) == 0, "po_count_byte_ranges_dev: sequence buffer must be 16-byte aligned");
+    PO_REQUIRE(byte >= 0 && byte <= 255, "po_count_byte_ranges_dev: byte value %d out of range", byte);
+    PO_HIP(hipSetDevice(ctx->device));
+    return po_launch_count_byte_ranges(ctx, d_seq, d_begins, d_ends, n_ranges, (uint32_t)byte, d_out);
+}
+
 extern "C" int po_profile_distances_dev(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n,
                                         uint32_t dim, const double* d_proto, int metric, double* d_out) {
     PO_REQUIRE(ctx != nullptr, "po_profile_distances_dev: ctx is NULL");

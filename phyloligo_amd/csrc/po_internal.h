@@ -110,6 +110,9 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
 int po_launch_profile_distances(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
                                 const double* d_proto, int metric, double* d_out);
 
+int po_launch_count_byte_ranges(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins, const uint64_t* d_ends, uint64_t n,
+                                uint32_t byte, uint64_t* d_out);
+
 // Working layout of stage 2: Ft[d][npad] = counts[n][d] / totals[n] (float64, zero padded).
 // skip_flag (may be NULL): device word with the largest count; the kernel does nothing when it is <= skip_upto
 int po_launch_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,

@@ -18,33 +18,59 @@ from .phyloligo import _context, read_fasta
 
 MIN_WINDOWS_PARALLEL = 20      # min_nb_w_per_fasta_for_mul_cpu, Kount.py:64: switches the coordinate rules
 
+_genomes = {}                  # (path, mtime, size) -> parsed FASTA + its sequence bytes resident in HBM
+
+
+def _load_genome(genome):
+    """The reference parses the assembly once per prototype and once per scan (Kount.py:306, :417); here the parsed
+    records and the device copy of the sequence bytes are kept per file, so every later step starts from HBM."""
+    import torch
+    st = os.stat(genome)
+    key = (os.path.abspath(genome), st.st_mtime_ns, st.st_size)
+    hit = _genomes.get(key)
+    if hit is None:
+        seq, offsets, titles = read_fasta(genome)
+        dev = torch.device("cuda", _context().device)
+        pad = (-len(seq)) % 16                                # the device buffer is 16-byte aligned and padded
+        d_seq = torch.from_numpy(np.concatenate([seq, np.zeros(pad, np.uint8)]) if pad else seq).to(dev)
+        d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+        _genomes.clear()                                      # one assembly at a time
+        hit = _genomes[key] = (seq, offsets, titles, d_seq, d_off)
+    return hit
+
 
 def record_windows(length, wsize, wstep):
     """(start, displayed_start, displayed_stop) of every window of one record (Kount.py:352-401): a record
     shorter than the window is one window; below 20 steps the 'serial' display rule applies, else the
     'parallel' one.  Windows start at range(0, len - wsize, wstep)."""
+    s, d0, d1 = record_windows_arrays(length, wsize, wstep)
+    return list(zip(s.tolist(), d0.tolist(), d1.tolist()))
+
+
+def record_windows_arrays(length, wsize, wstep):
+    """The same as three int64 arrays (a 20 Mb chromosome has 40 000 windows: no Python loop over them)."""
+    length = int(length)
     if length < wsize:
-        return [(0, 0, int(length))]
+        return np.zeros(1, np.int64), np.zeros(1, np.int64), np.full(1, length, np.int64)
     half_lo, half_hi = wsize / 2 - wstep / 2, wsize / 2 + wstep / 2
-    out = []
+    s = np.arange(0, length - wsize, wstep, dtype=np.int64)
     if length < MIN_WINDOWS_PARALLEL * wstep:
-        for s in range(0, length - wsize, wstep):
-            out.append((s, 1 if s == 0 else int(s + half_lo), length if s == length - wsize else int(s + half_hi)))
+        d0 = np.where(s == 0, 1, (s + half_lo).astype(np.int64))            # int(): truncation of a non-negative float
+        d1 = np.where(s == length - wsize, length, (s + half_hi).astype(np.int64))
     else:
-        for s in range(0, length - wsize, wstep):
-            start, stop = int(s + half_lo), int(s + half_hi)
-            edge = stop - wstep / 2 + wsize / 2
-            out.append((s, 1 if start == half_lo else start,
-                        length if (length - wstep <= edge <= length) else stop))
-    return out
+        start, stop = (s + half_lo).astype(np.int64), (s + half_hi).astype(np.int64)
+        edge = stop - wstep / 2 + wsize / 2
+        d0 = np.where(start == half_lo, 1, start)
+        d1 = np.where((length - wstep <= edge) & (edge <= length), length, stop)
+    return s, d0.astype(np.int64), d1.astype(np.int64)
 
 
 def compute_whole_composition(genome, pattern, strand, nb_jobs=1):
     """Kount.py:303-319: word counts summed over every record, then one frequency vector."""
-    seq, offsets, _ = read_fasta(genome)
-    counts, totals = _context().count_profiles(seq, offsets, pattern, strand)
-    c = counts.astype(np.int64).sum(axis=0)
-    t = int(totals.astype(np.int64).sum())
+    seq, offsets, _, d_seq, d_off = _load_genome(genome)
+    counts, totals = _context().count_profiles(d_seq[:len(seq)], d_off, pattern, strand)
+    c = counts.sum(dim=0, dtype=__import__("torch").int64).cpu().numpy()
+    t = int(totals.sum().item())
     return c.astype(np.float64) / np.float64(t) if t > 0 else np.zeros(c.shape[0], dtype=np.float64)
 
 
@@ -53,37 +79,40 @@ def sliding_windows_distances(genome, mcp_comparison, mth_dist="JSD", pattern="1
     """Kount.py:409-458, all windows at once: list of [id, displayed_start, displayed_stop, distance]."""
     strand = getattr(options, "strand", "both")
     n_max = float(getattr(options, "n_max_freq_in_windows", 0.4))
-    seq, offsets, titles = read_fasta(genome)
+    import torch
+    seq, offsets, titles, d_seq, _ = _load_genome(genome)
     ids, begins, ends, d0s, d1s = [], [], [], [], []
     for r, title in enumerate(titles):
         off, length = int(offsets[r]), int(offsets[r + 1] - offsets[r])
         parts = title.split(None, 1)
         rid = parts[0] if parts else ""
-        for s, d0, d1 in record_windows(length, windows_size, windows_step):
-            ids.append(rid)
-            begins.append(off + s)
-            ends.append(off + min(length, s + windows_size))
-            d0s.append(d0)
-            d1s.append(d1)
+        s, d0, d1 = record_windows_arrays(length, windows_size, windows_step)
+        ids.extend([rid] * len(s))
+        begins.append(off + s)
+        ends.append(off + np.minimum(length, s + windows_size))
+        d0s.append(d0)
+        d1s.append(d1)
     if not ids:
         return []
-    begins = np.asarray(begins, dtype=np.uint64)
-    ends = np.asarray(ends, dtype=np.uint64)
+    begins, ends = np.concatenate(begins), np.concatenate(ends)
+    d0s, d1s = np.concatenate(d0s).tolist(), np.concatenate(d1s).tolist()
     ctx = _context()
-    counts, totals = ctx.count_profiles_ranges(seq, begins, ends, pattern, strand)
-    raw = ctx.profile_distances(counts, totals, np.asarray(mcp_comparison, dtype=np.float64), mth_dist)
+    # windows, their profiles and their distances stay in HBM; 8 + 8 bytes per window come back
+    d_begins, d_ends = torch.from_numpy(begins).to(d_seq.device), torch.from_numpy(ends).to(d_seq.device)
+    counts, totals = ctx.count_profiles_ranges(d_seq[:len(seq)], d_begins, d_ends, pattern, strand)
+    raw = ctx.profile_distances(counts, totals, np.asarray(mcp_comparison, dtype=np.float64), mth_dist).cpu().numpy()
     dist = raw if mth_dist == "KL" else raw * 1000                        # display scaling of JSD / Eucl (:96, :123)
-    # the N gate (:295-300): proportion of upper-case 'N' in the window, by a prefix sum over the buffer
-    ncum = np.concatenate([[0], np.cumsum(seq == ord("N"), dtype=np.int64)])
-    lens = (ends - begins).astype(np.int64)
-    nfrac = (ncum[ends.astype(np.int64)] - ncum[begins.astype(np.int64)]) / np.maximum(lens, 1)
+    # the N gate (:295-300): proportion of upper-case 'N' in the window
+    n_in_window = ctx.count_byte_ranges(d_seq, d_begins, d_ends, ord("N")).cpu().numpy()
+    lens = ends - begins
+    nfrac = n_in_window / np.maximum(lens, 1)
     gated = (lens > 0) & (nfrac > n_max)
     if gated.any():
         k = api.normalise_pattern(pattern).count("1")
         if k ** 4 != 4 ** k:      # the reference builds a NaN vector of length k**4 (:300), which only fits k = 2, 4
             raise ValueError("operands could not be broadcast together with shapes (%d,) (%d,)" % (k ** 4, 4 ** k))
         dist = np.where(gated, 0.0, dist)                                 # NaN profile: every term is dropped
-    return [[i, a, b, d] for i, a, b, d in zip(ids, d0s, d1s, dist)]
+    return [list(t) for t in zip(ids, d0s, d1s, dist)]
 
 
 def get_cmd(argv=None):
