@@ -55,6 +55,25 @@ __device__ __forceinline__ uint32_t base_digit(uint32_t c) {
     return member ? d : 4u;
 }
 
+// the byte -> digit map, four entries per dword, for the wave's LDS copy (one 4-byte load per lane instead of four
+// evaluations of base_digit: this kernel is bound by instruction issue)
+struct DigitTable {
+    uint32_t w[64];
+    constexpr DigitTable() : w() {
+        for (int i = 0; i < 64; ++i) {
+            uint32_t e = 0;
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t c = (uint32_t)(i * 4 + j), x = (c & 0xDFu) - 0x41u;
+                const uint32_t member = (x < 32u) ? ((0x00080045u >> x) & 1u) : 0u;
+                const uint32_t d = (0x72u >> (((c >> 1) & 3u) * 2u)) & 3u;
+                e |= (member ? d : 4u) << (8 * j);
+            }
+            w[i] = e;
+        }
+    }
+};
+__constant__ DigitTable kDigitTable;
+
 // RUNS: -1 = a contiguous k-mer (one run, no gaps): the word is the low 2k bits of the forward register / the
 // whole 2W = 2k bit reverse register; 1..4 = that many (shift, mask, shift) runs, unrolled with the run parameters
 // in scalar registers; 0 = any number of runs (loop).
@@ -196,12 +215,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     // ---- stage + decode (aligned 16-byte loads, one table lookup per base) -------------------------
     // the byte -> digit map as a 256-byte LDS table of the wave (each lane evaluates four entries): a lookup costs
     // one LDS read instead of ~8 vector-ALU instructions, and this kernel is ALU-bound
-    {
-        uint32_t e = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e |= base_digit(lane * 4 + i) << (8 * i);
-        reinterpret_cast<uint32_t*>(dtab)[lane] = e;
-    }
+    reinterpret_cast<uint32_t*>(dtab)[lane] = kDigitTable.w[lane];
     if (P.sym && lane == 0) *mid_slot = 0xFFFFFFFFu;
     uint32_t mine_count = 0;
     const uint32_t W = P.window;
@@ -381,8 +395,11 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
         const uint32_t mid_word = P.sym ? *mid_slot : 0xFFFFFFFFu;
         auto bin = [&](uint32_t d) -> uint32_t {
             if (!P.sym) return hist[d];
-            uint32_t r = 0, w = d;                                  // reverse complement in the C,G,A,T digit coding
-            for (uint32_t i = 0; i < P.k; ++i) { r = (r << 2) | ((w & 3u) ^ 1u); w >>= 2; }
+            // reverse complement in the C,G,A,T digit coding: digits in reverse order, each XOR 1.  Bit reversal reverses
+            // the digits and the two bits inside each; swapping those back and flipping the low bit of every digit is
+            // one swap of odd and even bits with the even result bits complemented.
+            const uint32_t b = __brev(d) >> (32u - 2u * P.k);
+            const uint32_t r = (((b & 0x55555555u) << 1) | (((b >> 1) & 0x55555555u) ^ 0x55555555u)) & (P.dim - 1u);
             return hist[d] + hist[r] + (d == mid_word ? 1u : 0u);
         };
         if (rec_chunks == 1) {
