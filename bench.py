@@ -332,6 +332,10 @@ def main():
                        "env_knobs": knobs},
             "roofline": roof,
         }
+        if general is not None:      # the rate a ragged assembly gets, next to the headline (which needs equal totals)
+            result["value_general_kernel"] = general["pairs_per_s"]
+            result["value_general_kernel_note"] = ("same matrix through valu_tile_kernel<JSD> only; `value` is the integer-sum table "
+                                                    "kernel, which fixed-length synthetic contigs qualify for")
         if world > 1 or dist is not None:
             result["config"]["multi_gpu"] = {
                 "ranks_seen": ranks_seen, "backend": "gloo (rehearsal on one GPU)" if rehearsal else "nccl (RCCL)",
