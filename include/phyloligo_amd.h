@@ -227,6 +227,18 @@ int po_fasta_scan(const uint8_t* data, uint64_t len, uint64_t* n_records, uint64
 int po_fasta_extract(const uint8_t* data, uint64_t len, uint8_t* seq_out, uint64_t* offsets_out,
                      uint64_t* title_begin, uint64_t* title_end);
 
+/* ---- FASTA ingest on the device ------------------------------------------------------------ *
+ * The same records as po_fasta_scan / po_fasta_extract, from the raw file bytes already in HBM (16-byte aligned
+ * buffer): what Bio.SeqIO.parse(genome, "fasta") yields at bin/phyloligo.py:869, without a pass over the file on
+ * the host.  po_fasta_scan_dev sizes the outputs (it synchronises the stream once) and must precede
+ * po_fasta_extract_dev on the same buffer.  Title spans [title_begin, title_end) end at the line end: strip trailing
+ * white space when decoding a title.  Returns PO_EIO for text before the first record, PO_EUNSUPPORTED for a tab /
+ * vertical tab / form feed on a sequence line (rstrip() semantics that need the host parser).                   */
+int po_file_read(const char* path, uint8_t* buf, uint64_t len);   /* first len bytes of a file, read in parallel (host) */
+int po_fasta_scan_dev(po_ctx* ctx, const uint8_t* d_data, uint64_t len, uint64_t* n_records, uint64_t* seq_bytes);
+int po_fasta_extract_dev(po_ctx* ctx, const uint8_t* d_data, uint64_t len, uint8_t* d_seq, uint64_t* d_offsets,
+                         uint64_t* d_title_begin, uint64_t* d_title_end);
+
 /* numpy.savetxt(path, m, delimiter="\t") of bin/phyloligo.py:1061,1066: "%.18e" values, '\t'
  * between columns, '\n' after each row, "nan"/"inf" spelled as numpy spells them.            */
 int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, uint64_t ld, const char* path, int append);

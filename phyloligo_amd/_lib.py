@@ -76,6 +76,9 @@ SIGNATURES = {
     "po_pairwise_reserve": (_int, [_vp, _u64, _u32, _int]),
     "po_fasta_scan": (_int, [_vp, _u64, _c.POINTER(_u64), _c.POINTER(_u64)]),
     "po_fasta_extract": (_int, [_vp, _u64, _vp, _vp, _vp, _vp]),
+    "po_file_read": (_int, [_cp, _vp, _u64]),
+    "po_fasta_scan_dev": (_int, [_vp, _vp, _u64, _c.POINTER(_u64), _c.POINTER(_u64)]),
+    "po_fasta_extract_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     "po_write_mat_text": (_int, [_vp, _u64, _u64, _u64, _cp, _int]),
 }
 

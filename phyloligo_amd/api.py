@@ -363,6 +363,56 @@ def fasta_index(data):
     return seq, offsets, _Titles(np.asarray(buf[idx]) if idx.size else np.zeros(0, np.uint8), bounds)
 
 
+class _LineTitles:
+    """Record titles of a device-parsed FASTA file: spans [begin, line end) into the host copy of the file bytes,
+    right-stripped when decoded (the device leaves the trailing white space to whoever reads a title)."""
+
+    def __init__(self, buf, begins, ends):
+        self._buf, self._b, self._e = buf, begins, ends
+
+    def __len__(self):
+        return len(self._b)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self._buf[int(self._b[i]):int(self._e[i])].tobytes().rstrip(b" \t\n\r\x0b\x0c").decode("latin-1")
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+
+def fasta_index_dev(ctx, path):
+    """FASTA file -> (seq uint8 CUDA tensor, offsets int64 CUDA tensor [n+1], titles): the file bytes go to HBM as they
+    are and are parsed there (po_fasta_scan_dev / po_fasta_extract_dev).  Raises PhyloligoError(PO_EUNSUPPORTED) for the
+    one construct left to the host parser (tabs on sequence lines): callers fall back to fasta_index()."""
+    import os
+    import torch
+    lib = _lib.load()
+    size = os.path.getsize(path)
+    dev = torch.device("cuda", ctx.device)
+    buf = np.empty(size, dtype=np.uint8)
+    check(lib.po_file_read(str(path).encode(), _np_ptr(buf), size))
+    raw = torch.from_numpy(buf).to(dev)
+    nrec, nbytes = ctypes.c_uint64(), ctypes.c_uint64()
+    ctx._use_torch_stream()
+    check(lib.po_fasta_scan_dev(ctx._h, raw.data_ptr(), size, ctypes.byref(nrec), ctypes.byref(nbytes)))
+    seq = torch.empty(((nbytes.value + 15) // 16 * 16 or 16,), dtype=torch.uint8, device=dev)
+    offsets = torch.zeros((nrec.value + 1,), dtype=torch.int64, device=dev)
+    tb = torch.empty((max(1, nrec.value),), dtype=torch.int64, device=dev)
+    te = torch.empty((max(1, nrec.value),), dtype=torch.int64, device=dev)
+    check(lib.po_fasta_extract_dev(ctx._h, raw.data_ptr(), size, seq.data_ptr(), offsets.data_ptr(), tb.data_ptr(), te.data_ptr()))
+    titles = _LineTitles(buf, tb[:nrec.value].cpu().numpy(), te[:nrec.value].cpu().numpy())
+    return seq[:nbytes.value], offsets, titles
+
+
 def write_mat_text(path, m, append=False):
     """numpy.savetxt(path, m, delimiter="\\t") byte for byte (bin/phyloligo.py:1061,1066)."""
     lib = _lib.load()

@@ -94,6 +94,7 @@ extern "C" void po_ctx_destroy(po_ctx* ctx) {
     buf_free(&ctx->ws_pairdot);
     buf_free(&ctx->ws_pq);
     buf_free(&ctx->ws_thermo);
+    buf_free(&ctx->ws_fasta);
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     for (int i = 0; i < 2; ++i)
         if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);

@@ -62,6 +62,9 @@ struct po_ctx {
     po_buf ws_pq;                      // Kendall's word-pair table, cached per (dim, fold layout, format)
     uint64_t pq_key = ~0ull;
     po_buf ws_thermo;                  // Bray-Curtis thermometer plan (levels per word, element map)
+    po_buf ws_fasta;                   // per-block partial results of the on-device FASTA scan (po_fasta.hip)
+    const uint8_t* fasta_data = nullptr;   // the buffer po_fasta_scan_dev last sized, with its length and totals
+    uint64_t fasta_len = 0, fasta_records = 0, fasta_seq_bytes = 0;
     uint32_t fold_dim = 0, fold_gran = 0, fold_dim_f = 0, fold_dbl_at = 0;
     uint32_t* h_flag = nullptr;        // pinned host word for the fold decision
     void* h_stage[2] = {nullptr, nullptr};   // pinned staging buffers of the host-pointer entry points (device -> host rows)

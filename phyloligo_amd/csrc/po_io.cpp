@@ -10,6 +10,9 @@
 // .mat: numpy.savetxt(path, m, delimiter="\t") (/root/reference/phylopackage/bin/phyloligo.py:1061,
 // :1066) = "%.18e" per value, '\t' between columns, '\n' after every row, nothing else.
 #include <errno.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <charconv>
@@ -169,6 +172,43 @@ extern "C" int po_fasta_extract(const uint8_t* data, uint64_t len, uint8_t* seq_
         return PO_EINVAL;
     }
     return fasta_parallel(data, len, seq_out, offsets_out, title_begin, title_end, nullptr, nullptr);
+}
+
+// The first `len` bytes of a file into buf, read by the host threads the job may use (pread of disjoint ranges):
+// the raw FASTA bytes on their way to HBM for po_fasta_scan_dev / po_fasta_extract_dev.
+extern "C" int po_file_read(const char* path, uint8_t* buf, uint64_t len) {
+    if (!path || (!buf && len)) { po_set_error("po_file_read: NULL argument"); return PO_EINVAL; }
+    if (len == 0) return PO_OK;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { po_set_error("cannot open %s: %s", path, strerror(errno)); return PO_EIO; }
+    {   // a freshly allocated destination: ask for huge pages before the reader threads touch it (as in po_api.hip)
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(buf) + 4095u) & ~(uintptr_t)4095u;
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(buf) + len) & ~(uintptr_t)4095u;
+        if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
+    }
+    unsigned nthr = po_host_threads(16);
+    if (len / (8u << 20) + 1 < nthr) nthr = (unsigned)(len / (8u << 20) + 1);          // at least 8 MiB per thread
+    std::vector<int> rcs(nthr, PO_OK);
+    std::vector<std::thread> pool;
+    const uint64_t per = (len + nthr - 1) / nthr;
+    auto work = [&](unsigned t) {
+        uint64_t at = (uint64_t)t * per;
+        const uint64_t end = std::min<uint64_t>(len, at + per);
+        while (at < end) {
+            const ssize_t got = pread(fd, buf + at, end - at, (off_t)at);
+            if (got <= 0) { rcs[t] = PO_EIO; return; }
+            at += (uint64_t)got;
+        }
+    };
+    if (nthr == 1) work(0);
+    else {
+        for (unsigned t = 0; t < nthr; ++t) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    close(fd);
+    for (int rc : rcs)
+        if (rc != PO_OK) { po_set_error("read of %s failed: %s", path, strerror(errno)); return rc; }
+    return PO_OK;
 }
 
 // "%.18e" of one value into p, numpy spelling of non-finite values; returns the new end.

@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 from . import api
-from .phyloligo import _context, read_fasta
+from .phyloligo import _context, read_fasta, read_fasta_device
 
 MIN_WINDOWS_PARALLEL = 20      # min_nb_w_per_fasta_for_mul_cpu, Kount.py:64: switches the coordinate rules
 
@@ -29,13 +29,21 @@ def _load_genome(genome):
     key = (os.path.abspath(genome), st.st_mtime_ns, st.st_size)
     hit = _genomes.get(key)
     if hit is None:
-        seq, offsets, titles = read_fasta(genome)
-        dev = torch.device("cuda", _context().device)
-        pad = (-len(seq)) % 16                                # the device buffer is 16-byte aligned and padded
-        d_seq = torch.from_numpy(np.concatenate([seq, np.zeros(pad, np.uint8)]) if pad else seq).to(dev)
-        d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+        ingest = read_fasta_device(genome)
+        if ingest is not None:                                # parsed in HBM; only the record offsets come back
+            d_seq, d_off, titles = ingest
+            n_bytes = d_seq.numel()
+            offsets = d_off.cpu().numpy().astype(np.uint64)
+            d_seq = d_seq._base if d_seq._base is not None else d_seq      # the 16-byte padded allocation
+        else:
+            seq, offsets, titles = read_fasta(genome)
+            dev = torch.device("cuda", _context().device)
+            n_bytes = len(seq)
+            pad = (-len(seq)) % 16                            # the device buffer is 16-byte aligned and padded
+            d_seq = torch.from_numpy(np.concatenate([seq, np.zeros(pad, np.uint8)]) if pad else seq).to(dev)
+            d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
         _genomes.clear()                                      # one assembly at a time
-        hit = _genomes[key] = (seq, offsets, titles, d_seq, d_off)
+        hit = _genomes[key] = (n_bytes, offsets, titles, d_seq, d_off)
     return hit
 
 
@@ -67,8 +75,8 @@ def record_windows_arrays(length, wsize, wstep):
 
 def compute_whole_composition(genome, pattern, strand, nb_jobs=1):
     """Kount.py:303-319: word counts summed over every record, then one frequency vector."""
-    seq, offsets, _, d_seq, d_off = _load_genome(genome)
-    counts, totals = _context().count_profiles(d_seq[:len(seq)], d_off, pattern, strand)
+    n_bytes, offsets, _, d_seq, d_off = _load_genome(genome)
+    counts, totals = _context().count_profiles(d_seq[:n_bytes], d_off, pattern, strand)
     c = counts.sum(dim=0, dtype=__import__("torch").int64).cpu().numpy()
     t = int(totals.sum().item())
     return c.astype(np.float64) / np.float64(t) if t > 0 else np.zeros(c.shape[0], dtype=np.float64)
@@ -80,7 +88,7 @@ def sliding_windows_distances(genome, mcp_comparison, mth_dist="JSD", pattern="1
     strand = getattr(options, "strand", "both")
     n_max = float(getattr(options, "n_max_freq_in_windows", 0.4))
     import torch
-    seq, offsets, titles, d_seq, _ = _load_genome(genome)
+    n_bytes, offsets, titles, d_seq, _ = _load_genome(genome)
     ids, begins, ends, d0s, d1s = [], [], [], [], []
     for r, title in enumerate(titles):
         off, length = int(offsets[r]), int(offsets[r + 1] - offsets[r])
@@ -99,7 +107,7 @@ def sliding_windows_distances(genome, mcp_comparison, mth_dist="JSD", pattern="1
     ctx = _context()
     # windows, their profiles and their distances stay in HBM; 8 + 8 bytes per window come back
     d_begins, d_ends = torch.from_numpy(begins).to(d_seq.device), torch.from_numpy(ends).to(d_seq.device)
-    counts, totals = ctx.count_profiles_ranges(d_seq[:len(seq)], d_begins, d_ends, pattern, strand)
+    counts, totals = ctx.count_profiles_ranges(d_seq[:n_bytes], d_begins, d_ends, pattern, strand)
     raw = ctx.profile_distances(counts, totals, np.asarray(mcp_comparison, dtype=np.float64), mth_dist).cpu().numpy()
     dist = raw if mth_dist == "KL" else raw * 1000                        # display scaling of JSD / Eucl (:96, :123)
     # the N gate (:295-300): proportion of upper-case 'N' in the window

@@ -53,6 +53,20 @@ def read_fasta(genome):
         del data
 
 
+def read_fasta_device(genome):
+    """The same records through the on-device parser: (seq CUDA uint8, offsets CUDA int64[n+1], titles), or None when
+    the file has the one construct that parser leaves to the host (tabs on sequence lines) or is empty."""
+    from ._lib import PhyloligoError, PO_EUNSUPPORTED
+    if os.path.getsize(genome) == 0:
+        return None
+    try:
+        return api.fasta_index_dev(_context(), genome)
+    except PhyloligoError as exc:
+        if exc.status == PO_EUNSUPPORTED:
+            return None
+        raise
+
+
 def compute_frequencies(mthdrun, large, genome, pattern, strand, distchunksize=250, threads_max=4, workdir="."):
     """phyloligo.py:980-997.  Returns (frequencies, freq_name); freq_name is always None here
     (no on-disk frequency container: the count matrix lives in HBM / host memory)."""
@@ -63,10 +77,19 @@ def compute_frequencies(mthdrun, large, genome, pattern, strand, distchunksize=2
         print("Error, strand parameter of selectd_strand() should be choose from {'both', 'minus', 'plus'}",
               file=sys.stderr)
         sys.exit(1)
-    seq, offsets, titles = read_fasta(genome)
     ctx = _context()
-    counts, totals = ctx.count_profiles(seq, offsets, pattern, strand)
-    freq = ctx.frequencies(counts, totals)
+    ingest = read_fasta_device(genome)
+    if ingest is not None:
+        # file bytes -> HBM -> records -> profiles -> frequencies without the sequence ever being walked on the host
+        d_seq, d_off, titles = ingest
+        d_counts, d_totals = ctx.count_profiles(d_seq, d_off, pattern, strand)
+        freq = ctx.frequencies(d_counts, d_totals).cpu().numpy()
+        counts = d_counts.cpu().numpy().view(np.uint32)
+        totals = d_totals.cpu().numpy().view(np.uint64)
+    else:
+        seq, offsets, titles = read_fasta(genome)
+        counts, totals = ctx.count_profiles(seq, offsets, pattern, strand)
+        freq = ctx.frequencies(counts, totals)
     return ProfileMatrix(freq, counts, totals, titles), None
 
 

@@ -1,0 +1,124 @@
+"""FASTA ingest on the device (po_fasta_scan_dev / po_fasta_extract_dev) against the host parser of the same library
+(po_fasta_scan / po_fasta_extract, Biopython SimpleFastaParser semantics restated in csrc/po_io.cpp): sequence bytes,
+record offsets and titles must be identical for every input, across the 4 KiB blocks the kernels cut the file into."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import phyloligo_amd as pa
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def both(ctx, tmp_path, data, name="x.fa"):
+    import phyloligo_amd as pa
+    path = tmp_path / name
+    path.write_bytes(data)
+    want_seq, want_off, want_titles = pa.fasta_index(np.frombuffer(data, dtype=np.uint8)) if data else (np.zeros(0, np.uint8), np.zeros(1, np.uint64), [])
+    seq, off, titles = pa.api.fasta_index_dev(ctx, str(path))
+    assert np.array_equal(seq.cpu().numpy(), want_seq)
+    assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+    assert list(titles) == list(want_titles)
+    return seq, off, titles
+
+
+CASES = {
+    "plain": b">a one\nACGT\nAC\n>b\nGGGG\n",
+    "crlf": b">a one \r\nACGT\r\nAC\r\n>b\t tab title \r\nGG GG\r\n",
+    "no_final_newline": b">a\nACGT\n>b\nTT",
+    "header_at_eof": b">a\nACGT\n>b",
+    "header_at_eof_nl": b">a\nACGT\n>b\n",
+    "empty_records": b">a\n>b\n\n>c\nAC\n\n\n>d\n",
+    "leading_blank": b"\n  \n\r\n>a\nAC\n",
+    "inner_gt": b">a\nAC>GT\nA>\n>b\nTT\n",
+    "spaces_inside": b">a\nA C G T\n  ACGT  \n",
+    "lowercase_n": b">a\nacgtnNNNNacgt\n",
+    "only_blank": b"\n\n  \n",
+    "single_byte_lines": b">a\nA\nC\nG\nT\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_hand_built_cases(ctx, tmp_path, name):
+    both(ctx, tmp_path, CASES[name])
+
+
+def test_long_lines_and_many_records_cross_blocks(ctx, tmp_path):
+    rng = np.random.default_rng(1)
+    acgt = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    parts = []
+    for i in range(300):
+        parts.append(b">rec%d some description that is fairly long %s\n" % (i, b"x" * int(rng.integers(0, 90))))
+        n = int(rng.choice([0, 1, 15, 16, 17, 4095, 4096, 4097, 20000, 70])) if i % 7 else 300000
+        s = acgt[rng.integers(0, 5, size=n)].tobytes()
+        if i % 3 == 0:
+            parts.append(s + b"\n")                                    # one long line
+        else:
+            w = int(rng.integers(1, 200))
+            parts.append(b"".join(s[p:p + w] + (b"\r\n" if i % 5 == 0 else b"\n") for p in range(0, len(s), w)))
+    data = b"".join(parts)
+    assert len(data) > 8 << 20
+    seq, off, titles = both(ctx, tmp_path, data)
+    assert len(titles) == 300 and titles[0].startswith("rec0 some")
+
+
+def test_fuzz_against_host_parser(ctx, tmp_path):
+    rng = np.random.default_rng(7)
+    alphabet = np.frombuffer(b"ACGTNacgtn>  \r", dtype=np.uint8)
+    for case in range(120):
+        lines = []
+        if rng.random() < 0.3:
+            lines += [b"", b"  ", b"\r"][: int(rng.integers(0, 4))]
+        for _ in range(int(rng.integers(0, 60))):
+            r = rng.random()
+            if r < 0.25:
+                lines.append(b">" + alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 40)))].tobytes().replace(b"\r", b"t"))
+            elif r < 0.35:
+                lines.append(b"" if rng.random() < 0.5 else b"   ")
+            else:
+                body = alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 300)))].tobytes()
+                lines.append(body.lstrip(b">") if rng.random() < 0.8 else body)
+        if not lines or not lines[0].startswith(b">"):
+            lines.insert(len([l for l in lines[:3] if l.strip() == b""]) if False else 0, b">first")
+        sep = b"\r\n" if case % 4 == 0 else b"\n"
+        data = sep.join(lines) + (sep if case % 3 else b"")
+        both(ctx, tmp_path, data, "f%d.fa" % case)
+
+
+def test_errors_and_the_host_only_construct(ctx, tmp_path):
+    import phyloligo_amd as pa
+    from phyloligo_amd._lib import PhyloligoError, PO_EIO, PO_EUNSUPPORTED
+    p = tmp_path / "junk.fa"
+    p.write_bytes(b"ACGT\n>a\nACGT\n")
+    with pytest.raises(PhyloligoError) as e:
+        pa.api.fasta_index_dev(ctx, str(p))
+    assert e.value.status == PO_EIO
+    with pytest.raises(PhyloligoError):
+        pa.fasta_index(np.frombuffer(p.read_bytes(), dtype=np.uint8))          # the host parser refuses it too
+    p = tmp_path / "tab.fa"
+    p.write_bytes(b">a\nAC\tGT\n")
+    with pytest.raises(PhyloligoError) as e:
+        pa.api.fasta_index_dev(ctx, str(p))
+    assert e.value.status == PO_EUNSUPPORTED
+    p.write_bytes(b">a\ttitle with a tab\nACGT\n")                               # tabs in titles are fine
+    seq, off, titles = pa.api.fasta_index_dev(ctx, str(p))
+    assert titles[0] == "a\ttitle with a tab" and bytes(seq.cpu().numpy()) == b"ACGT"
+
+
+def test_device_ingest_feeds_stage_one(ctx, tmp_path):
+    """File bytes -> HBM -> records -> profiles without the sequence ever being on the host: same counts as the host path."""
+    from phyloligo_amd import synthetic
+    seq, off = synthetic.contig_bytes(3000, 2000, seed=77)
+    p = tmp_path / "asm.fa"
+    p.write_bytes(synthetic.fasta_bytes(seq, off))
+    import phyloligo_amd as pa
+    d_seq, d_off, titles = pa.api.fasta_index_dev(ctx, str(p))
+    assert len(titles) == 3000 and titles[2999] == "c0002999"
+    counts, totals = ctx.count_profiles(d_seq, d_off, "1111", "both")
+    hc, ht = ctx.count_profiles(seq, off, "1111", "both")
+    assert np.array_equal(counts.cpu().numpy().astype(np.uint32), hc) and np.array_equal(totals.cpu().numpy().astype(np.uint64), ht)
