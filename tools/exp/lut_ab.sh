@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 cp phyloligo_amd/libphyloligo_amd.so /tmp/orig.so
-for v in lut_1 lut_4 lut_8 orig; do
+for v in "$@" orig; do
   if [ $v = orig ]; then cp /tmp/orig.so phyloligo_amd/libphyloligo_amd.so; else cp tools/exp/lib$v.so phyloligo_amd/libphyloligo_amd.so; fi
   echo "== $v"; timeout -k 10 200 python tools/one_launch.py 50000 JSD 4 2>&1 | grep JSD | tail -2
 done
