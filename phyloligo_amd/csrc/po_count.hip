@@ -25,7 +25,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kPerLane = 32;                       // window starts per lane
 constexpr int kTile = 64 * kPerLane;               // 2048 staged positions carrying a window start, per wave
-constexpr int kSpan = kTile - 16;                  // window starts per pass (16 B alignment slack)
+constexpr int kSpan = kTile - 32;                  // window starts per pass: 16 B alignment slack + 16 so that no start of the
+                                                   // last lane needs a base beyond the 2048 staged ones when W <= 16 (fast path)
 constexpr int kPasses = 1;                         // passes per chunk.  A wave can walk several spans of one record before it
                                                    // flushes its histogram (fewer global atomics on long records); measured at 8:
                                                    // 115 vs 84 us on 2 kb contigs, 397 vs 349 us on a ragged 0.33 Gb assembly -
@@ -41,6 +42,7 @@ struct CountParams {
     uint32_t src_shift[PO_MAX_RUNS];
     uint32_t dst_shift[PO_MAX_RUNS];
     uint32_t mask[PO_MAX_RUNS];
+    uint32_t le_src[4], le_dst[4];   // the first four runs for a window packed first-base-lowest (fast path)
     int strand;
     uint32_t n_seqs;
     uint64_t total_bytes;
@@ -89,6 +91,29 @@ __device__ __forceinline__ uint32_t word_index(REG reg, const CountParams& P) {
     for (uint32_t r = 0; r < P.nruns; ++r)
         idx |= ((uint32_t)(reg >> P.src_shift[r]) & P.mask[r]) << P.dst_shift[r];
     return idx;
+}
+
+// The same for a window packed the other way round (base x of the window at bits [2x, 2x+2), fast path): the result
+// is the word index with its k digits in reverse order, digits_reversed() of the index above.
+template <int RUNS>
+__device__ __forceinline__ uint32_t word_index_le(uint32_t win, const CountParams& P) {
+    if (RUNS < 0) return win & (P.dim - 1u);
+    uint32_t idx = 0;
+#pragma unroll
+    for (int r = 0; r < (RUNS > 0 ? RUNS : 1); ++r) idx |= ((win >> P.le_src[r]) & P.mask[r]) << P.le_dst[r];
+    return idx;
+}
+// k base-4 digits of d in reverse order: bit reversal reverses the digits and the two bits inside each; swap those back
+__device__ __forceinline__ uint32_t digits_reversed(uint32_t d, uint32_t k) {
+    const uint32_t b = __brev(d) >> (32u - 2u * k);
+    return ((b & 0x55555555u) << 1) | ((b >> 1) & 0x55555555u);
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void lds_add(uint32_t addr, uint32_t v) {   // ds_add_u32 at a byte address of the LDS
+    __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // record i is bytes [begins[i], ends[i]) of the sequence buffer (contiguous records: ends = begins + 1;
@@ -178,14 +203,19 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                                                          uint32_t* __restrict__ counts,
                                                          unsigned long long* __restrict__ totals) {
     extern __shared__ __align__(16) uint32_t smem[];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    // the wave index as a scalar: everything derived from it (chunk, record, lengths, addresses) then lives in scalar
+    // registers and is loaded by scalar loads instead of 64 identical vector lanes
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave >= waves_per_block) return;
-    const uint32_t per_wave_words = kStage / 4 + 64 + 4 + (LDS_HIST ? P.dim : 0);
-    uint32_t* mine = smem + wave * per_wave_words;
+    // LDS: the histograms of the workgroup's waves first (each aligned to its own size, so that a bin address is an OR),
+    // then per wave the staged digits, the byte -> digit table and the junction slot
+    constexpr uint32_t kAuxWords = kStage / 4 + 64 + 4;
+    uint32_t* hist = smem + (LDS_HIST ? wave * P.dim : 0);         // [dim] when LDS_HIST
+    uint32_t* mine = smem + (LDS_HIST ? waves_per_block * P.dim : 0) + wave * kAuxWords;
     uint8_t* codes = reinterpret_cast<uint8_t*>(mine);            // [kStage]
     uint8_t* dtab = reinterpret_cast<uint8_t*>(mine + kStage / 4); // [256] byte -> digit
     uint32_t* mid_slot = mine + kStage / 4 + 64;                   // word of the self-mirrored junction window (symmetric mode)
-    uint32_t* hist = mine + kStage / 4 + 64 + 4;                   // [dim] when LDS_HIST
 
     const uint32_t b = blockIdx.x * waves_per_block + wave;
     const uint32_t nchunks = chunk_start[P.n_seqs];
@@ -215,16 +245,107 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     // ---- stage + decode (aligned 16-byte loads, one table lookup per base) -------------------------
     // the byte -> digit map as a 256-byte LDS table of the wave (each lane evaluates four entries): a lookup costs
     // one LDS read instead of ~8 vector-ALU instructions, and this kernel is ALU-bound
-    reinterpret_cast<uint32_t*>(dtab)[lane] = kDigitTable.w[lane];
     if (P.sym && lane == 0) *mid_slot = 0xFFFFFFFFu;
-    uint32_t mine_count = 0;
+    uint32_t mine_count = 0;                                        // words counted by this lane (general path)
+    uint32_t uni_count = 0;                                         // words accounted for by wave-uniform arithmetic (fast path)
+    bool slow_junction = false;
     const uint32_t W = P.window;
     constexpr bool want_plus = MODE != 1, want_minus = MODE != 0;
     const uint32_t per_word = P.sym ? 2u : 1u;                      // a forward word also stands for its mirror window
+    constexpr bool kFast = LDS_HIST && NARROW && MODE == 0 && RUNS != 0 && kPasses == 1;
+    bool fast_done = false;                                         // wave uniform: the histogram is indexed digit-reversed
     for (int64_t p_lo = c_lo; p_lo < c_hi; p_lo += kSpan) {         // wave uniform; LDS is in order within a wave
     const int64_t p_hi = min(p_lo + (int64_t)kSpan, L);
     const uint64_t a0 = (off + (uint64_t)p_lo) & ~(uint64_t)15;    // 16 B aligned staging origin
     const int64_t pos0 = (int64_t)a0 - (int64_t)off;               // record position of staged byte 0
+    __builtin_amdgcn_wave_barrier();
+    // ---- fast path: forward words of a window of at most 16 positions, nothing but A/C/G/T in the 2048 staged bytes --
+    // Every lane loads its own 32 bases (two aligned 16-byte loads), turns them into digits four at a time with bit
+    // operations (no table lookups), packs them into a 64-bit string, takes the next lane's first 16 bases with one DPP
+    // move and reads the window of every start out of registers: 3 vector instructions per start (funnel shift, bin
+    // address as AND-OR onto the aligned histogram base, the start's bit of the lane's validity mask as the addend).
+    // The histogram is indexed by the word with its digits reversed (first base lowest), undone when it is written out.
+    // Word totals and the junction words come from wave-uniform arithmetic on the record's last W-1 bases.
+    const uint32_t hist_addr = lds_addr(hist);
+    if (kFast && a0 + kTile <= P.total_bytes && (hist_addr & (P.dim * 4u - 1u)) == 0u) {      // wave uniform
+        const uint4 r0 = *reinterpret_cast<const uint4*>(seq + a0 + lane * kPerLane);
+        const uint4 r1 = *reinterpret_cast<const uint4*>(seq + a0 + lane * kPerLane + 16);
+        const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        uint32_t dg[8], bad = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t code = (w[j] >> 1) & 0x03030303u;                       // A0 C1 T2 G3 in either case
+            bad |= (w[j] & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, code);   // the letter that code stands for
+            dg[j] = __builtin_amdgcn_perm(0u, 0x01030002u, code);                  // C0 G1 A2 T3
+        }
+        if (!__any((int)(bad != 0u))) {
+            // 16 digit bytes -> 32 bits, first base lowest
+            auto pack16 = [](uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) -> uint32_t {
+                const uint32_t t0 = d0 | (d0 >> 6), t1 = d1 | (d1 >> 6), t2 = d2 | (d2 >> 6), t3 = d3 | (d3 >> 6);   // bytes 0, 2: two digits
+                const uint32_t e01 = __builtin_amdgcn_perm(t1, t0, 0x06040200u), e23 = __builtin_amdgcn_perm(t3, t2, 0x06040200u);
+                const uint32_t f01 = e01 | (e01 >> 4), f23 = e23 | (e23 >> 4);     // bytes 0, 2: four digits
+                return __builtin_amdgcn_perm(f23, f01, 0x06040200u);
+            };
+            const uint32_t plo = pack16(dg[0], dg[1], dg[2], dg[3]), phi = pack16(dg[4], dg[5], dg[6], dg[7]);
+            const uint32_t halo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)plo, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+            // starts that count, in staged coordinates: [st_lo, st_hi) (wave uniform), this lane's part as a bit mask
+            const int32_t st_lo = (int32_t)(p_lo - pos0);
+            const int32_t st_hi = max(st_lo, (int32_t)(min(p_hi, L - (int64_t)W + 1) - pos0));
+            uni_count += (uint32_t)(st_hi - st_lo) * per_word;
+            const int32_t s_lo = max(st_lo - (int32_t)(lane * kPerLane), 0);
+            const int32_t s_hi = min(st_hi - (int32_t)(lane * kPerLane), (int32_t)kPerLane);
+            if (s_hi > s_lo) {
+                const uint32_t span = (uint32_t)(s_hi - s_lo);
+                const uint32_t vmask = (span >= 32u ? 0xFFFFFFFFu : ((1u << span) - 1u)) << s_lo;
+                if (RUNS < 0) {
+                    const uint32_t m4 = (P.dim - 1u) << 2;
+                    uint32_t hbase;                                 // in a vector register: v_and_or_b32 takes one scalar operand
+                    asm("v_mov_b32 %0, %1" : "=v"(hbase) : "s"(hist_addr));
+#pragma unroll
+                    for (int sft = 0; sft < kPerLane; ++sft) {
+                        const uint32_t x = sft == 0 ? plo << 2 : sft <= 16 ? __builtin_amdgcn_alignbit(phi, plo, 2 * sft - 2)
+                                                                          : __builtin_amdgcn_alignbit(halo, phi, 2 * sft - 34);
+                        lds_add((x & m4) | hbase, (vmask >> sft) & 1u);
+                    }
+                } else {
+#pragma unroll
+                    for (int sft = 0; sft < kPerLane; ++sft) {
+                        const uint32_t win = sft == 0 ? plo : sft < 16 ? __builtin_amdgcn_alignbit(phi, plo, 2 * sft)
+                                           : sft == 16 ? phi : __builtin_amdgcn_alignbit(halo, phi, 2 * sft - 32);
+                        lds_add(hist_addr + word_index_le<RUNS>(win, P) * 4u, (vmask >> sft) & 1u);
+                    }
+                }
+            }
+            // junction windows of seq + revcomp(seq) (symmetric mode; see the general code below for the pairing rule)
+            if (P.strand == PO_STRAND_BOTH && p_hi == L && W > 1) {
+                const int64_t ts64 = L - (int64_t)W + 1 - pos0;     // staged index of the first of the record's last W-1 bases
+                if (ts64 >= 0) {
+                    const uint32_t st = (uint32_t)ts64 & 31u, lt = (uint32_t)ts64 >> 5;
+                    const uint32_t sel = st < 16u ? __builtin_amdgcn_alignbit(phi, plo, 2u * st)
+                                                  : __builtin_amdgcn_alignbit(halo, phi, 2u * st - 32u);
+                    const uint32_t tb = 2u * (W - 1u);
+                    const uint32_t tmask = (1u << tb) - 1u;
+                    const uint32_t tail = (uint32_t)__builtin_amdgcn_readlane((int)sel, (int)lt) & tmask;   // last W-1 bases, first lowest
+                    const uint32_t rct = (digits_reversed(tail, W - 1u) ^ 0x55555555u) & tmask;         // their reverse complement
+                    const uint64_t J = (uint64_t)tail | ((uint64_t)rct << tb);
+                    if (lane < W - 1u) {
+                        const uint32_t idx = word_index_le<RUNS>((uint32_t)(J >> (2u * lane)), P);
+                        if (2u * lane + 2u < W) lds_add(hist_addr + idx * 4u, 1u);
+                        else if (2u * lane + 2u == W) *mid_slot = digits_reversed(idx, P.k);
+                    }
+                    uni_count += 2u * ((W - 1u) >> 1) + ((W & 1u) ? 0u : 1u);
+                } else {                                           // the tail starts before the staged range: general code below
+                    *reinterpret_cast<uint4*>(codes + lane * kPerLane) = make_uint4(dg[0], dg[1], dg[2], dg[3]);
+                    *reinterpret_cast<uint4*>(codes + lane * kPerLane + 16) = make_uint4(dg[4], dg[5], dg[6], dg[7]);
+                    slow_junction = true;
+                }
+            }
+            fast_done = true;
+        }
+    }
+    if (!fast_done) {
+    slow_junction = true;
+    reinterpret_cast<uint32_t*>(dtab)[lane] = kDigitTable.w[lane];
     __builtin_amdgcn_wave_barrier();
     // all of the lane's 16-byte loads first (up to three HBM round trips in flight at once), then the decoding
     constexpr int kVecPerLane = (kStage / 16 + 63) / 64;
@@ -346,11 +467,14 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
         }
     }
 
+    }   // general path
+    __builtin_amdgcn_wave_barrier();
+
     // ---- junction words of seq + revcomp(seq) (-s both), by the chunk holding the record end ----
     // Symmetric mode: the W-1 junction windows are mirror images of each other (start p <-> 2L - W - p), so only the
     // first of each pair is added (the write-out doubles it); for even W the middle window is its own mirror and
     // spells a self-paired word, which is added once, after the doubling (mid_word).
-    if (P.strand == PO_STRAND_BOTH && p_hi == L && lane < W - 1) {    // the pass that holds the record end
+    if (slow_junction && P.strand == PO_STRAND_BOTH && p_hi == L && lane < W - 1) {    // the pass that holds the record end
         const int64_t p = L - (int64_t)W + 1 + (int64_t)lane;       // start in the 2L-long virtual string
         const bool first_of_pair = 2 * p < 2 * L - (int64_t)W, middle = 2 * p == 2 * L - (int64_t)W;
         if (p >= 0 && p < L && p + (int64_t)W <= 2 * L && (!P.sym || first_of_pair || middle)) {
@@ -371,7 +495,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                     *mid_slot = idx;
                     ++mine_count;
                 } else {
-                    if (LDS_HIST) atomicAdd(&hist[idx], 1u);
+                    if (LDS_HIST) atomicAdd(&hist[fast_done ? digits_reversed(idx, P.k) : idx], 1u);
                     else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                     mine_count += per_word;
                 }
@@ -382,7 +506,9 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     }   // passes
 
     // ---- totals: wave reduce, one store / atomic per chunk ----------------------------------------
-    for (int o = 32; o > 0; o >>= 1) mine_count += __shfl_down(mine_count, o, 64);
+    if (slow_junction)                                              // wave uniform: somebody counted per lane
+        for (int o = 32; o > 0; o >>= 1) mine_count += __shfl_down(mine_count, o, 64);
+    mine_count += uni_count;
     if (lane == 0) {
         if (rec_chunks == 1) totals[rec] = mine_count;
         else if (mine_count) atomicAdd(&totals[rec], (unsigned long long)mine_count);
@@ -402,6 +528,32 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
             const uint32_t r = (((b & 0x55555555u) << 1) | (((b >> 1) & 0x55555555u) ^ 0x55555555u)) & (P.dim - 1u);
             return hist[d] + hist[r] + (d == mid_word ? 1u : 0u);
         };
+        if (fast_done) {
+            // the histogram is indexed by the digit-reversed word: outputs d0..d0+3 differ in their last digit = the first
+            // of the reversed word; the mirror window's word, reversed, is d with every digit complemented: one aligned quad
+            const uint32_t cmask = 0x55555555u & (P.dim - 1u), top = 2u * P.k - 2u;
+            if (rec_chunks == 1) {
+                for (uint32_t d0 = lane * 4; d0 < P.dim; d0 += 256) {
+                    const uint32_t base = digits_reversed(d0, P.k);
+                    uint32_t v[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) v[j] = hist[base + (j << top)];
+                    if (P.sym) {
+                        const uint4 q = *reinterpret_cast<const uint4*>(hist + ((d0 ^ cmask) & ~3u));
+                        v[0] += q.y; v[1] += q.x; v[2] += q.w; v[3] += q.z;
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) v[j] += (d0 + j == mid_word) ? 1u : 0u;
+                    }
+                    *reinterpret_cast<uint4*>(row + d0) = make_uint4(v[0], v[1], v[2], v[3]);
+                }
+            } else {                                               // consecutive lanes, consecutive bins: dense atomics
+                for (uint32_t d = lane; d < P.dim; d += 64) {
+                    uint32_t v = hist[digits_reversed(d, P.k)];
+                    if (P.sym) v += hist[d ^ cmask] + (d == mid_word ? 1u : 0u);
+                    if (v) atomicAdd(&row[d], v);
+                }
+            }
+        } else
         if (rec_chunks == 1) {
             for (uint32_t d = lane * 4; d < P.dim; d += 256)
                 *reinterpret_cast<uint4*>(row + d) = make_uint4(bin(d), bin(d + 1), bin(d + 2), bin(d + 3));
@@ -448,6 +600,11 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     P.window = pat.window; P.k = pat.k; P.dim = pat.dim; P.nruns = pat.nruns;
     for (uint32_t r = 0; r < pat.nruns; ++r) {
         P.src_shift[r] = pat.src_shift[r]; P.dst_shift[r] = pat.dst_shift[r]; P.mask[r] = pat.mask[r];
+    }
+    for (uint32_t r = 0; r < pat.nruns && r < 4; ++r) {            // the same runs for a window packed first-base-lowest
+        const uint32_t len = (uint32_t)__builtin_popcount(pat.mask[r]) / 2;
+        P.le_src[r] = 2 * (pat.window - len) - pat.src_shift[r];    // 2 x (first window position of the run)
+        P.le_dst[r] = 2 * (pat.k - len) - pat.dst_shift[r];         // 2 x (rank of its first digit)
     }
     for (uint32_t i = 0; i < pat.k; ++i) P.patbits |= 1u << pat.ones[i];
     P.strand = strand;
