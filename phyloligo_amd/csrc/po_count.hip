@@ -5,9 +5,10 @@
 //   (/root/reference/phylopackage/bin/phyloligo.py:124-149, :683, :601-631, :653)
 // with one byte scan: HBM-bound (1 byte per base read once, 4*4^k bytes per record written).
 //
-// Work decomposition: a record of L bases is cut into ceil(L/2032) chunks, one WAVE per chunk
-// (records of a 2 kb assembly are one chunk each; a 10 Mb chromosome is 4.9k chunks spread over
-// the chip).  A wave stages its bytes with aligned 16-byte loads, decodes them once to 2-bit
+// Work decomposition: a record of L bases is cut into ceil(L/2016) chunks, one WAVE per chunk
+// (records of a 2 kb assembly are one chunk each; a 10 Mb chromosome is 5k chunks spread over
+// the chip).  Fast path (forward words, window <= 16, only A/C/G/T in the chunk; see the kernel): digits by bit
+// operations, windows out of a packed register string.  General path: a wave stages its bytes with aligned 16-byte loads, decodes them once to 2-bit
 // digits (C=0,G=1,A=2,T=3; anything else breaks a word) in LDS, then every lane slides a 2*W-bit
 // rolling register over 32 consecutive window starts.  Waves never wait for each other (no
 // workgroup barrier); four of them share a workgroup only to share its launch.  Both strands come out of the same
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
             // junction windows of seq + revcomp(seq) (symmetric mode; see the general code below for the pairing rule)
             if (P.strand == PO_STRAND_BOTH && p_hi == L && W > 1) {
                 const int64_t ts64 = L - (int64_t)W + 1 - pos0;     // staged index of the first of the record's last W-1 bases
-                if (ts64 >= 0) {
+                if (ts64 >= 0 && L >= (int64_t)W - 1) {           // the W-1 bases exist and are staged
                     const uint32_t st = (uint32_t)ts64 & 31u, lt = (uint32_t)ts64 >> 5;
                     const uint32_t sel = st < 16u ? __builtin_amdgcn_alignbit(phi, plo, 2u * st)
                                                   : __builtin_amdgcn_alignbit(halo, phi, 2u * st - 32u);
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                         else if (2u * lane + 2u == W) *mid_slot = digits_reversed(idx, P.k);
                     }
                     uni_count += 2u * ((W - 1u) >> 1) + ((W & 1u) ? 0u : 1u);
-                } else {                                           // the tail starts before the staged range: general code below
+                } else {                                           // shorter record, or the tail starts before the staged range: general code below
                     *reinterpret_cast<uint4*>(codes + lane * kPerLane) = make_uint4(dg[0], dg[1], dg[2], dg[3]);
                     *reinterpret_cast<uint4*>(codes + lane * kPerLane + 16) = make_uint4(dg[4], dg[5], dg[6], dg[7]);
                     slow_junction = true;
