@@ -37,6 +37,32 @@ __global__ __launch_bounds__(256) void fill_tiles(double* __restrict__ out, uint
     }
 }
 
+// (d) the matrix-core kernels' pattern: 8-byte stores, one instruction = 2 rows x 32 columns (two 256-byte segments), as the
+// 32x32 accumulator layout gives them (column = lane & 31, rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5));
+// (e) the same bytes as one row x 64 columns per instruction (512 contiguous bytes).
+template <int WIDE>
+__global__ __launch_bounds__(256) void fill_tri_acc(po_tile_args A, double* __restrict__ out, uint32_t n) {
+    uint32_t ti, tj;
+    po_tile_coords(A, 128, blockIdx.x, ti, tj);
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+    for (int o = 0; o < 2; ++o) {
+        if (o == 1 && ti == tj) break;
+        const uint64_t i0 = (uint64_t)(o ? tj : ti) * 128 + w * 32, j0 = (uint64_t)(o ? ti : tj) * 128;
+        if (!WIDE) {
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    out[(i0 + rl) * n + j0 + cb * 32 + lr] = (double)reg;
+                }
+        } else {
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 32; ++r) out[(i0 + r) * n + j0 + cb * 64 + lane] = (double)r;
+        }
+    }
+}
+
 int main() {
     const uint32_t n = 50048;                      // multiple of 128
     double* out;
@@ -47,17 +73,19 @@ int main() {
     memset(&A, 0, sizeof(A));
     A.n = A.npad = n; A.row_end = A.col_end = n; A.triangular = 1;
     const uint32_t T = n / 128;
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
         for (int it = 0; it < 4; ++it) {
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(fill_flat, dim3(256 * 16), dim3(256), 0, 0, reinterpret_cast<double2*>(out), (uint64_t)n * n / 2);
+            else if (mode == 3) hipLaunchKernelGGL(fill_tri_acc<0>, dim3(T * (T + 1) / 2), dim3(256), 0, 0, A, out, n);
+            else if (mode == 4) hipLaunchKernelGGL(fill_tri_acc<1>, dim3(T * (T + 1) / 2), dim3(256), 0, 0, A, out, n);
             else if (mode == 2) hipLaunchKernelGGL(fill_tri, dim3(T * (T + 1) / 2), dim3(256), 0, 0, A, out, n);
             else hipLaunchKernelGGL(fill_tiles, dim3((n / 128) * (n / 128)), dim3(256), 0, 0, out, n, n / 128);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms;
             hipEventElapsedTime(&ms, e0, e1);
-            printf("%s: %.3f ms  %.2f TB/s\n", mode == 0 ? "flat 16-byte fill" : mode == 1 ? "128x128 tiles, 1 KiB row pieces" : "triangle + mirror, XCD-banded order", ms,
+            printf("%s: %.3f ms  %.2f TB/s\n", mode == 0 ? "flat 16-byte fill" : mode == 1 ? "128x128 tiles, 1 KiB row pieces" : mode == 2 ? "triangle + mirror, XCD-banded order" : mode == 3 ? "triangle + mirror, 8-byte stores, 2 rows x 256 B per instruction" : "triangle + mirror, 8-byte stores, 1 row x 512 B per instruction", ms,
                    (double)n * n * 8 / (ms * 1e-3) / 1e12);
         }
     }
