@@ -788,7 +788,7 @@ static int copy_rows_to_host(po_ctx* ctx, const uint8_t* d_src, size_t src_pitch
     }
     const uint64_t rows_per = kStage / row_bytes;
     const uint64_t n_chunks = (rows + rows_per - 1) / rows_per;
-    const unsigned n_thr = po_host_threads(8);
+    const unsigned n_thr = po_host_threads(14);
     auto issue = [&](uint64_t c) -> hipError_t {
         const uint64_t r0 = c * rows_per, nr = (rows - r0 < rows_per) ? rows - r0 : rows_per;
         return hipMemcpy2DAsync(ctx->h_stage[c & 1], row_bytes, d_src + r0 * src_pitch, src_pitch, row_bytes, nr,
