@@ -23,7 +23,6 @@
 
 namespace {
 
-constexpr int kThreads = 256;
 constexpr int kPerLane = 32;                       // window starts per lane
 constexpr int kTile = 64 * kPerLane;               // 2048 staged positions carrying a window start, per wave
 constexpr int kSpan = kTile - 32;                  // window starts per pass: 16 B alignment slack + 16 so that no start of the
@@ -127,22 +126,39 @@ __device__ __forceinline__ uint32_t chunks_of(const uint64_t* begins, const uint
 // (1) per-1024-record block sums, (2) scan of the block sums, (3) local scan + block offset.
 __global__ __launch_bounds__(256) void scan_block_sums_kernel(const uint64_t* __restrict__ begins,
                                                               const uint64_t* __restrict__ ends, uint32_t n,
-                                                              uint32_t* __restrict__ blocksum) {
-    __shared__ uint32_t wsum[4];
+                                                              uint32_t* __restrict__ blocksum,
+                                                              uint32_t* __restrict__ blockmax) {
+    __shared__ uint32_t wsum[4], wmax[4];
     const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
-    uint32_t s = 0;
+    uint32_t s = 0, m = 0;
     for (uint32_t e = 0; e < 4; ++e)
-        if (base + e < n) s += chunks_of(begins, ends, base + e);
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+        if (base + e < n) { const uint32_t c = chunks_of(begins, ends, base + e); s += c; m = max(m, c); }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); m = max(m, (uint32_t)__shfl_down(m, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = s; wmax[threadIdx.x >> 6] = m; }
     __syncthreads();
-    if (threadIdx.x == 0) blocksum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        blocksum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        blockmax[blockIdx.x] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    }
 }
 
 __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ blocksum, uint32_t nb,
-                                                         uint32_t* __restrict__ total) {
+                                                         uint32_t* __restrict__ total,
+                                                         const uint32_t* __restrict__ blockmax, uint32_t* __restrict__ max_chunks) {
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x;
+    {                                                               // most chunks in one record (1: no record spans chunks)
+        uint32_t m = 0;
+        for (uint32_t i = t; i < nb; i += 1024) m = max(m, blockmax[i]);
+        part[t] = m;
+        __syncthreads();
+        for (uint32_t d = 512; d > 0; d >>= 1) {
+            if (t < d) part[t] = max(part[t], part[t + d]);
+            __syncthreads();
+        }
+        if (t == 0) *max_chunks = part[0];
+        __syncthreads();
+    }
     uint32_t carry = 0;
     for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {                    // 1024 block sums (1M records) per round
         const uint32_t v = (b0 + t < nb) ? blocksum[b0 + t] : 0u;
@@ -196,10 +212,11 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
 // MODE: which rolling registers the slide keeps - 0 forward only (plus strand, or both strands in symmetric mode),
 //       1 reverse only (minus strand), 2 both.
 template <bool LDS_HIST, bool NARROW, int MODE, int RUNS>
-__global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restrict__ seq,
+__global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__ seq,
                                                          const uint64_t* __restrict__ begins,
                                                          const uint64_t* __restrict__ ends,
                                                          const uint32_t* __restrict__ chunk_start,
+                                                         const uint32_t* __restrict__ max_chunks,
                                                          CountParams P, uint32_t waves_per_block,
                                                          uint32_t* __restrict__ counts,
                                                          unsigned long long* __restrict__ totals) {
@@ -208,19 +225,24 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     // the wave index as a scalar: everything derived from it (chunk, record, lengths, addresses) then lives in scalar
     // registers and is loaded by scalar loads instead of 64 identical vector lanes
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wave >= waves_per_block) return;
     // LDS: the histograms of the workgroup's waves first (each aligned to its own size, so that a bin address is an OR),
-    // then per wave the staged digits, the byte -> digit table and the junction slot
+    // then per wave the staged digits, the byte -> digit table and two slots (junction word, group total)
     constexpr uint32_t kAuxWords = kStage / 4 + 64 + 4;
-    uint32_t* hist = smem + (LDS_HIST ? wave * P.dim : 0);         // [dim] when LDS_HIST
     uint32_t* mine = smem + (LDS_HIST ? waves_per_block * P.dim : 0) + wave * kAuxWords;
     uint8_t* codes = reinterpret_cast<uint8_t*>(mine);            // [kStage]
     uint8_t* dtab = reinterpret_cast<uint8_t*>(mine + kStage / 4); // [256] byte -> digit
-    uint32_t* mid_slot = mine + kStage / 4 + 64;                   // word of the self-mirrored junction window (symmetric mode)
 
     const uint32_t b = blockIdx.x * waves_per_block + wave;
     const uint32_t nchunks = chunk_start[P.n_seqs];
-    if (b >= nchunks) return;                                      // grid is an upper bound
+    // Some record spans several chunks (wave uniform, from the scan): the waves of a workgroup that hold consecutive chunks
+    // of ONE record then count into the histogram of the first of them, which writes the record's row once - with plain
+    // stores when the whole record lies inside the workgroup (up to 16 chunks = 32 kb), so that global atomics are left to
+    // records that cross workgroups.  Two workgroup barriers in that case; none for assemblies of single-chunk records.
+    const bool multi = LDS_HIST && *max_chunks > 1u;
+    if (b >= nchunks) {                                            // grid is an upper bound
+        if (multi) { __syncthreads(); __syncthreads(); }
+        return;
+    }
     // record of chunk b = last record with chunk_start <= b.  When every record so far is a single chunk (any
     // assembly of contigs up to 2 kb) that is record b itself: two loads instead of a 16-step dependent search.
     uint32_t lo = 0, hi = P.n_seqs;
@@ -239,14 +261,22 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     const int64_t L = (int64_t)(ends[rec] - off);
     const int64_t c_lo = (int64_t)chunk * kChunkSpan;              // window starts [c_lo, c_hi) are ours, kSpan per pass
     const int64_t c_hi = min(c_lo + (int64_t)kChunkSpan, L);
+    const uint32_t lead = multi ? wave - min(wave, chunk) : wave;          // first wave of this record in the workgroup
+    const bool whole = multi ? (chunk <= wave && wave - chunk + rec_chunks <= waves_per_block) : rec_chunks == 1;
+    uint32_t* hist = smem + (LDS_HIST ? lead * P.dim : 0);         // [dim] when LDS_HIST
+    uint32_t* mid_slot = smem + (LDS_HIST ? waves_per_block * P.dim : 0) + lead * kAuxWords + kStage / 4 + 64;
+    // mid_slot[0]: word of the self-mirrored junction window (symmetric mode); mid_slot[1]: words of the group (whole records)
 
-    if (LDS_HIST)
-        for (uint32_t d = lane * 4; d < P.dim; d += 256) *reinterpret_cast<uint4*>(hist + d) = make_uint4(0, 0, 0, 0);
+    if (LDS_HIST) {
+        uint32_t* own = smem + wave * P.dim;
+        for (uint32_t d = lane * 4; d < P.dim; d += 256) *reinterpret_cast<uint4*>(own + d) = make_uint4(0, 0, 0, 0);
+    }
+    if (lane < 2) mine[kStage / 4 + 64 + lane] = lane == 0 ? 0xFFFFFFFFu : 0u;
+    if (multi) __syncthreads();
 
     // ---- stage + decode (aligned 16-byte loads, one table lookup per base) -------------------------
     // the byte -> digit map as a 256-byte LDS table of the wave (each lane evaluates four entries): a lookup costs
     // one LDS read instead of ~8 vector-ALU instructions, and this kernel is ALU-bound
-    if (P.sym && lane == 0) *mid_slot = 0xFFFFFFFFu;
     uint32_t mine_count = 0;                                        // words counted by this lane (general path)
     uint32_t uni_count = 0;                                         // words accounted for by wave-uniform arithmetic (fast path)
     bool slow_junction = false;
@@ -254,7 +284,11 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     constexpr bool want_plus = MODE != 1, want_minus = MODE != 0;
     const uint32_t per_word = P.sym ? 2u : 1u;                      // a forward word also stands for its mirror window
     constexpr bool kFast = LDS_HIST && NARROW && MODE == 0 && RUNS != 0 && kPasses == 1;
-    bool fast_done = false;                                         // wave uniform: the histogram is indexed digit-reversed
+    bool fast_done = false;                                         // wave uniform: this chunk went through the fast path
+    // A histogram shared by the chunks of one record is indexed digit-reversed whenever the fast path exists in this
+    // kernel (a chunk that has to take the general path then reverses its words one by one); a single-chunk record's
+    // histogram is indexed the way its one chunk was counted.
+    const bool force_le = kFast && multi && rec_chunks > 1u && (lds_addr(hist) & (P.dim * 4u - 1u)) == 0u;
     for (int64_t p_lo = c_lo; p_lo < c_hi; p_lo += kSpan) {         // wave uniform; LDS is in order within a wave
     const int64_t p_hi = min(p_lo + (int64_t)kSpan, L);
     const uint64_t a0 = (off + (uint64_t)p_lo) & ~(uint64_t)15;    // 16 B aligned staging origin
@@ -425,7 +459,8 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                     const int s = i - (int)(W - 1);                     // window start index of this lane (uniform)
                     if (s >= 0 && (uint32_t)(s - s_lo) < span) {
                         if (want_plus) {
-                            const uint32_t idx = word_index<reg_t, RUNS>(fwd, P);
+                            uint32_t idx = word_index<reg_t, RUNS>(fwd, P);
+                            if (force_le) idx = digits_reversed(idx, P.k);
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                         }
@@ -450,7 +485,8 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                 if (s >= 0) {
                     if (run >= W && s >= s_lo && s < s_hi) {
                         if (want_plus) {
-                            const uint32_t idx = word_index<reg_t, RUNS>(fwd, P);
+                            uint32_t idx = word_index<reg_t, RUNS>(fwd, P);
+                            if (force_le) idx = digits_reversed(idx, P.k);
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                             mine_count += per_word;
@@ -496,7 +532,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                     *mid_slot = idx;
                     ++mine_count;
                 } else {
-                    if (LDS_HIST) atomicAdd(&hist[fast_done ? digits_reversed(idx, P.k) : idx], 1u);
+                    if (LDS_HIST) atomicAdd(&hist[(fast_done || force_le) ? digits_reversed(idx, P.k) : idx], 1u);
                     else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                     mine_count += per_word;
                 }
@@ -512,14 +548,18 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
     mine_count += uni_count;
     if (lane == 0) {
         if (rec_chunks == 1) totals[rec] = mine_count;
+        else if (whole) atomicAdd(&mid_slot[1], mine_count);       // LDS: the group's first wave writes the sum below
         else if (mine_count) atomicAdd(&totals[rec], (unsigned long long)mine_count);
     }
 
-    // ---- flush ----------------------------------------------------------------------------------
-    if (LDS_HIST) {
+    // ---- flush: the first wave of the record's group, once every wave of the group has counted ------
+    if (multi) __syncthreads();
+    if (LDS_HIST && wave == lead) {
         __builtin_amdgcn_wave_barrier();
         uint32_t* row = counts + (uint64_t)rec * P.dim;
-        const uint32_t mid_word = P.sym ? *mid_slot : 0xFFFFFFFFu;
+        const uint32_t mid_word = P.sym ? mid_slot[0] : 0xFFFFFFFFu;
+        if (whole && rec_chunks > 1 && lane == 0) totals[rec] = mid_slot[1];
+        const bool le = fast_done || force_le;
         auto bin = [&](uint32_t d) -> uint32_t {
             if (!P.sym) return hist[d];
             // reverse complement in the C,G,A,T digit coding: digits in reverse order, each XOR 1.  Bit reversal reverses
@@ -529,11 +569,11 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
             const uint32_t r = (((b & 0x55555555u) << 1) | (((b >> 1) & 0x55555555u) ^ 0x55555555u)) & (P.dim - 1u);
             return hist[d] + hist[r] + (d == mid_word ? 1u : 0u);
         };
-        if (fast_done) {
+        if (le) {
             // the histogram is indexed by the digit-reversed word: outputs d0..d0+3 differ in their last digit = the first
             // of the reversed word; the mirror window's word, reversed, is d with every digit complemented: one aligned quad
             const uint32_t cmask = 0x55555555u & (P.dim - 1u), top = 2u * P.k - 2u;
-            if (rec_chunks == 1) {
+            if (whole) {
                 for (uint32_t d0 = lane * 4; d0 < P.dim; d0 += 256) {
                     const uint32_t base = digits_reversed(d0, P.k);
                     uint32_t v[4];
@@ -555,7 +595,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const uint8_t* __restri
                 }
             }
         } else
-        if (rec_chunks == 1) {
+        if (whole) {
             for (uint32_t d = lane * 4; d < P.dim; d += 256)
                 *reinterpret_cast<uint4*>(row + d) = make_uint4(bin(d), bin(d + 1), bin(d + 2), bin(d + 3));
         } else {
@@ -578,20 +618,22 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     if (max_chunks >= (1ull << 31)) { po_set_error("input too large for one launch"); return PO_EUNSUPPORTED; }
 
     const uint32_t nb = (uint32_t)((n_seqs + 1023) / 1024);
-    int rc = po_buf_reserve(ctx, &ctx->ws_aux, (n_seqs + 1 + nb + 1) * sizeof(uint32_t));
+    int rc = po_buf_reserve(ctx, &ctx->ws_aux, (n_seqs + 1 + 2 * (uint64_t)nb + 2) * sizeof(uint32_t));
     if (rc) return rc;
     uint32_t* chunk_start = static_cast<uint32_t*>(ctx->ws_aux.p);
     uint32_t* blocksum = chunk_start + n_seqs + 1;
     uint32_t* total = blocksum + nb;
+    uint32_t* blockmax = total + 1;
+    uint32_t* d_max_chunks = blockmax + nb;
 
     // rows of single-chunk records are written whole by their wave; only multi-chunk records (rare:
     // longer than 2 kb) accumulate with atomics and need zeros first.  Zero everything: 1 memset.
     PO_HIP(hipMemsetAsync(d_counts, 0, n_seqs * (uint64_t)pat.dim * sizeof(uint32_t), ctx->stream));
     PO_HIP(hipMemsetAsync(d_totals, 0, n_seqs * sizeof(uint64_t), ctx->stream));
 
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_begins, d_ends, (uint32_t)n_seqs, blocksum);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_begins, d_ends, (uint32_t)n_seqs, blocksum, blockmax);
     PO_CHECK_LAUNCH("scan_block_sums_kernel");
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, blocksum, nb, total);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, blocksum, nb, total, blockmax, d_max_chunks);
     PO_CHECK_LAUNCH("scan_sums_kernel");
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_begins, d_ends, (uint32_t)n_seqs, blocksum, total, chunk_start);
     PO_CHECK_LAUNCH("scan_apply_kernel");
@@ -618,7 +660,7 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     const bool lds_hist = pat.dim <= kMaxLdsBins;
     const size_t per_wave = kStage + 256 + 16 + (lds_hist ? (size_t)pat.dim * 4 : 0);
     uint32_t wpb = (uint32_t)((80u << 10) / per_wave);                // waves per workgroup within 80 KiB of LDS
-    wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
+    wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);                          // up to 4 consecutive chunks of one record share a flush (8 and 16 measured slower)
     const size_t shmem = per_wave * wpb;
     const uint32_t grid = (uint32_t)((max_chunks + wpb - 1) / wpb);
     unsigned long long* tot = reinterpret_cast<unsigned long long*>(d_totals);
@@ -626,7 +668,7 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     const int mode = (strand == PO_STRAND_PLUS || P.sym) ? 0 : (strand == PO_STRAND_MINUS ? 1 : 2);
     auto launch = [&](auto k) -> int {
         PO_SHMEM(ctx, k, shmem);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), shmem, ctx->stream, d_seq, d_begins, d_ends, chunk_start, P, wpb, d_counts, tot);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(64 * wpb), shmem, ctx->stream, d_seq, d_begins, d_ends, chunk_start, d_max_chunks, P, wpb, d_counts, tot);
         return PO_OK;
     };
     int lrc = PO_OK;
