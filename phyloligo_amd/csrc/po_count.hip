@@ -261,7 +261,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
     const int64_t L = (int64_t)(ends[rec] - off);
     const int64_t c_lo = (int64_t)chunk * kChunkSpan;              // window starts [c_lo, c_hi) are ours, kSpan per pass
     const int64_t c_hi = min(c_lo + (int64_t)kChunkSpan, L);
-    const uint32_t lead = multi ? wave - min(wave, chunk) : wave;          // first wave of this record in the workgroup
+    const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)(multi ? wave - min(wave, chunk) : wave));   // first wave of this record in the workgroup
     const bool whole = multi ? (chunk <= wave && wave - chunk + rec_chunks <= waves_per_block) : rec_chunks == 1;
     uint32_t* hist = smem + (LDS_HIST ? lead * P.dim : 0);         // [dim] when LDS_HIST
     uint32_t* mid_slot = smem + (LDS_HIST ? waves_per_block * P.dim : 0) + lead * kAuxWords + kStage / 4 + 64;
@@ -310,7 +310,8 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const uint32_t code = (w[j] >> 1) & 0x03030303u;                       // A0 C1 T2 G3 in either case
-            bad |= (w[j] & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, code);   // the letter that code stands for
+            // bad |= upper(w) ^ the letter that code stands for, as one three-input bit operation (0xF6 = a | (b ^ c))
+            bad = __builtin_amdgcn_bitop3_b32(bad, w[j] & 0xDFDFDFDFu, __builtin_amdgcn_perm(0u, 0x47544341u, code), 0xF6);
             dg[j] = __builtin_amdgcn_perm(0u, 0x01030002u, code);                  // C0 G1 A2 T3
         }
         if (!__any((int)(bad != 0u))) {
