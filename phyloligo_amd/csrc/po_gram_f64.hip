@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
                 } else {  // PO_SC: 1 - Pearson correlation of the centred ranks; constant row -> NaN
                     v = 1.0 - g / sqrt(ni[m][reg] * nj);
                 }
-                if (j_ok && i >= A.row_begin && i < n_rows) out[(i - A.row_begin) * A.ld_out + (j - A.col_begin)] = (OUT)v;
+                if (j_ok && i >= A.row_begin && i < n_rows) po_out_store(&out[(i - A.row_begin) * A.ld_out + (j - A.col_begin)], (OUT)v);
                 if (mirror) wl[lc * kTrStride + m * 16 + lg + 4 * reg] = v;
             }
         }
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
                 if (vec_mir && i + 1 < n_rows) {
                     *reinterpret_cast<double2*>(row + (i - A.row_begin)) = w;
                 } else {
-                    if (i >= A.row_begin && i < n_rows) row[i - A.row_begin] = (OUT)w.x;
-                    if (i + 1 >= A.row_begin && i + 1 < n_rows) row[i + 1 - A.row_begin] = (OUT)w.y;
+                    if (i >= A.row_begin && i < n_rows) po_out_store(&row[i - A.row_begin], (OUT)w.x);
+                    if (i + 1 >= A.row_begin && i + 1 < n_rows) po_out_store(&row[i + 1 - A.row_begin], (OUT)w.y);
                 }
             }
         }

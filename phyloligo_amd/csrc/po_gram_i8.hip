@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
                 y = fma(0.5 * y, fma(-(x * y), y, 1.0), y);
                 v = (G == trr && G == tc) ? (x > 0.0 ? 0.0 : G / x) : 1.0 - G * y;
             }
-            if (c_ok && r >= A.row_begin && r < n_rows) out[(r - A.row_begin) * A.ld_out + (c - A.col_begin)] = (OUT)v;
+            if (c_ok && r >= A.row_begin && r < n_rows) po_out_store(&out[(r - A.row_begin) * A.ld_out + (c - A.col_begin)], (OUT)v);
             if (mirror) wl[lr * kTrStride + rl] = v;
         }
         if (mirror) {                                      // wave-private scratch; LDS operations of a wave run in order
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
                 const double w = wl[jr * kTrStride + lr];
                 const uint64_t cm = jw + nn * 32 + jr, r = iw + lr;
                 if (cm >= A.col_begin && cm < n_cols && r >= A.row_begin && r < n_rows)
-                    mir[(cm - A.col_begin) * A.ld_mirror + (r - A.row_begin)] = (OUT)w;
+                    po_out_store(&mir[(cm - A.col_begin) * A.ld_mirror + (r - A.row_begin)], (OUT)w);
             }
         }
     }

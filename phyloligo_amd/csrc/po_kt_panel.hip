@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kThreads, 4) void kt_panel_tile_kernel(po_tile_args
             const uint64_t rr = ri + m * 32 + rl;
             const double dr = drs[m][reg];
             const double v = po_kt_value((double)g[m][reg], dr, dc, po_kt_rs(dr), rsc);
-            if (c_ok && rr >= A.row_begin && rr < n_rows) out[(rr - A.row_begin) * A.ld_out + (c - A.col_begin)] = (OUT)v;
+            if (c_ok && rr >= A.row_begin && rr < n_rows) po_out_store(&out[(rr - A.row_begin) * A.ld_out + (c - A.col_begin)], (OUT)v);
             if (mirror) wl[lr * 33 + rl] = v;
         }
         if (mirror) {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kThreads, 4) void kt_panel_tile_kernel(po_tile_args
                 const double w = wl[jr * 33 + lr];
                 const uint64_t cm = cj + jr, rr = ri + m * 32 + lr;
                 if (cm >= A.col_begin && cm < n_cols && rr >= A.row_begin && rr < n_rows)
-                    mir[(cm - A.col_begin) * A.ld_mirror + (rr - A.row_begin)] = (OUT)w;
+                    po_out_store(&mir[(cm - A.col_begin) * A.ld_mirror + (rr - A.row_begin)], (OUT)w);
             }
         }
     }

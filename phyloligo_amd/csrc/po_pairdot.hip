@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
                     const double num = (r1t[m * 32 + rl] + tc1) - 2.0 * G;      // exact integers
                     v = (r == c) ? 0.0 : (num * E.scalar) / (r0t[m * 32 + rl] + tc0);
                 }
-                if (c_ok && r >= A.row_begin && r < n_rows) out[(r - A.row_begin) * A.ld_out + (c - A.col_begin)] = (OUT)v;
+                if (c_ok && r >= A.row_begin && r < n_rows) po_out_store(&out[(r - A.row_begin) * A.ld_out + (c - A.col_begin)], (OUT)v);
                 if (mirror) wl[lr * kTrStride + rl] = v;
             }
             if (mirror) {                                  // wave-private scratch; LDS operations of a wave run in order
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
                     const double w = wl[jr * kTrStride + lr];
                     const uint64_t cm = jw + nn * 32 + jr, r = iw + m * 32 + lr;
                     if (cm >= A.col_begin && cm < n_cols && r >= A.row_begin && r < n_rows)
-                        mir[(cm - A.col_begin) * A.ld_mirror + (r - A.row_begin)] = (OUT)w;
+                        po_out_store(&mir[(cm - A.col_begin) * A.ld_mirror + (r - A.row_begin)], (OUT)w);
                 }
             }
         }

@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 cp phyloligo_amd/libphyloligo_amd.so /tmp/orig.so
-for v in "$@" orig; do
+for v in nont orig nont orig; do
   if [ $v = orig ]; then cp /tmp/orig.so phyloligo_amd/libphyloligo_amd.so; else cp tools/exp/lib$v.so phyloligo_amd/libphyloligo_amd.so; fi
-  for p in 0 96; do echo "== $v permits $p"; PO_PD_PERMITS=$p timeout -k 5 90 python tools/exp/kt_only.py 2>&1 | grep -E "KT"; done
+  echo "== $v: $(timeout -k 5 200 python tools/exp/nt_ab.py 2>&1 | grep JSD)"
 done
 cp /tmp/orig.so phyloligo_amd/libphyloligo_amd.so
