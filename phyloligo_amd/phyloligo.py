@@ -222,10 +222,105 @@ def get_cmd(argv=None):
     return params
 
 
+def main_distributed(params):
+    """The same job on the GPUs of one node, one process per GPU (launched by torch.distributed.run: WORLD_SIZE > 1).
+
+    The reference spreads row slices over joblib workers that all see the frequency matrix (gen_even_slices,
+    phyloligo.py:424,516).  Here every rank profiles its own block of contigs, ONE all-gather moves the exact count
+    matrix, the block grid is dealt out like a round-robin tournament (dist.RowBlockPlan: every unordered pair evaluated
+    once in the whole job), the transposed blocks go to the ranks whose rows they complete, and every rank writes its
+    rows of the output: straight into its byte range of the float32 container (--large memmap), or in rank order into the
+    text matrix.  PO_CLI_REHEARSAL=1: all ranks on GPU 0 with gloo collectives (a one-GPU box can run the code path)."""
+    import torch
+    import torch.distributed as tdist
+    from .dist import RowBlockPlan
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    rehearsal = os.environ.get("PO_CLI_REHEARSAL") == "1"
+    local = 0 if rehearsal else int(os.environ.get("LOCAL_RANK", "0"))
+    if params.mthdrun not in ("joblib", "hip") or params.large == "h5py":
+        if rank == 0:
+            print("Error, the multi-GPU run supports --method joblib|hip with --large None|memmap", file=sys.stderr)
+        sys.exit(1)
+    if params.strand not in STRANDS or params.dist not in METRICS:
+        sys.exit(1)
+    torch.cuda.set_device(local)
+    if rehearsal:
+        tdist.init_process_group("gloo")
+    else:
+        tdist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    global _ctx
+    _ctx = api.Context(local)
+    ctx, dev = _ctx, torch.device("cuda", local)
+    say = print if rank == 0 else (lambda *a, **k: None)
+    say("Using pattern {}".format(params.pattern))
+    if rank == 0 and not os.path.isdir(params.workdir):
+        os.makedirs(params.workdir)
+    say("Computing frequencies")
+    ingest = read_fasta_device(params.genome)
+    if ingest is not None:
+        d_seq, d_off, _ = ingest
+    else:
+        seq, offsets, _ = read_fasta(params.genome)
+        d_seq, d_off = torch.from_numpy(seq).to(dev), torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    n = int(d_off.numel()) - 1
+    plan = RowBlockPlan(n, world)
+    lo, hi = plan.rows(rank)
+    my_off = (d_off[lo:hi + 1] - d_off[lo]).contiguous()
+    my_seq = d_seq[int(d_off[lo]):int(d_off[hi])]
+    if my_seq.data_ptr() % 16:                                  # the kernels read aligned 16-byte vectors
+        my_seq = my_seq.clone()
+    my_counts, my_totals = ctx.count_profiles(my_seq, my_off, params.pattern, params.strand)
+    if rehearsal:
+        counts, totals = plan.all_gather_profiles(my_counts.cpu(), my_totals.cpu(), tdist)
+        counts, totals = counts.to(dev), totals.to(dev)
+    else:
+        counts, totals = plan.all_gather_profiles(my_counts, my_totals, tdist)
+    say("Computing Pairwise distances")
+    dtype = torch.float32 if params.large == "memmap" else torch.float64
+    slab, mirrors = plan.allocate(rank, dev, dtype)
+    plan.compute(ctx, counts, totals, params.dist, rank, slab, mirrors)
+    torch.cuda.synchronize(dev)
+    if rehearsal:                                               # gloo moves host tensors
+        slab_h, mirrors_h = slab.cpu(), [None if m is None else m.cpu() for m in mirrors]
+        del slab, mirrors
+        rows = plan.complete_rows(rank, slab_h, mirrors_h, tdist).numpy()
+    else:
+        plan.complete_rows(rank, slab, mirrors, tdist)
+        torch.cuda.synchronize(dev)
+        del mirrors
+        rows = slab.cpu().numpy()
+    if params.out_freq_file and rank == 0:
+        print("Writing frequency matrix")
+        api.write_mat_text(params.out_freq_file, ctx.frequencies(counts, totals).cpu().numpy())
+    if params.large == "memmap":
+        if rank == 0:
+            with open(params.out_file, "wb") as f:
+                f.truncate(n * n * 4)
+        tdist.barrier()
+        fd = os.open(params.out_file, os.O_RDWR)
+        try:
+            flat, done = memoryview(np.ascontiguousarray(rows, dtype=np.float32).reshape(-1)).cast("B"), 0
+            while done < len(flat):
+                done += os.pwrite(fd, flat[done:done + (1 << 30)], lo * n * 4 + done)
+        finally:
+            os.close(fd)
+        tdist.barrier()
+    else:
+        say("Writing distance matrix")
+        for r in range(world):                                  # rank order = row order
+            if r == rank and (hi > lo or r == 0):
+                api.write_mat_text(params.out_file, rows.reshape(hi - lo, n), append=r > 0)
+            tdist.barrier()
+    tdist.destroy_process_group()
+    return 0
+
+
 def main(argv=None):
     params = get_cmd(argv)
     if type(params.pattern) == int:                      # :1040-1041
         params.pattern = str("1") * params.pattern
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return main_distributed(params)
     print("Using pattern {}".format(params.pattern))
     if not os.path.isdir(params.workdir):
         os.makedirs(params.workdir)

@@ -176,3 +176,33 @@ def test_bc_from_frequencies_takes_the_thermometer_path():
         b, st_b = ctx.pairwise_freq(ctx.frequencies(counts, totals), "BC", want_stats=True)
         assert st_a["kernel_id"] == 9 and st_b["kernel_id"] == 9
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_multi_gpu_cli_rehearsal(tmp_path, ranks):
+    """python -m torch.distributed.run -m phyloligo_amd: one process per GPU, every rank profiles its contigs, one
+    all-gather, tournament row blocks, row-completing exchange, every rank writes its rows.  Here the ranks share this
+    one GPU over gloo (PO_CLI_REHEARSAL=1); the files must equal the single-process run byte for byte - text matrix,
+    frequency matrix and the float32 container (ragged lengths, a block boundary that is not a multiple of anything)."""
+    import subprocess
+    import sys
+    from phyloligo_amd import phyloligo as P
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(77)
+    fa = tmp_path / "asm.fa"
+    with open(fa, "wb") as fh:
+        for i in range(517):
+            s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(rng.integers(300, 5000)))].tobytes()
+            fh.write(b">c%d\n" % i + s + b"\n")
+    env = dict(os.environ, PO_CLI_REHEARSAL="1", MASTER_ADDR="127.0.0.1", PYTHONPATH=root)
+    for metric, large, name in (("JSD", "None", "jsd.mat"), ("KT", "None", "kt.mat"), ("Eucl", "memmap", "eucl.f32")):
+        ref, got = tmp_path / ("ref_" + name), tmp_path / ("got_" + name)
+        args = ["-i", str(fa), "-k", "4", "-d", metric, "--method", "joblib", "--large", large]
+        assert P.main(args + ["-o", str(ref), "-q", str(ref) + ".freq"]) == 0
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                              "--master-addr", "127.0.0.1", "--master-port", str(29540 + ranks), "-m", "phyloligo_amd"] + args +
+                             ["-o", str(got), "-q", str(got) + ".freq"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        assert out.stdout.count("Computing Pairwise distances") == 1            # rank 0 speaks
+        assert open(ref, "rb").read() == open(got, "rb").read(), (metric, large)
+        assert open(str(ref) + ".freq", "rb").read() == open(str(got) + ".freq", "rb").read()
