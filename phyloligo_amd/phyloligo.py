@@ -283,12 +283,17 @@ def main_distributed(params):
     if rehearsal:                                               # gloo moves host tensors
         slab_h, mirrors_h = slab.cpu(), [None if m is None else m.cpu() for m in mirrors]
         del slab, mirrors
-        rows = plan.complete_rows(rank, slab_h, mirrors_h, tdist).numpy()
+        slab = plan.complete_rows(rank, slab_h, mirrors_h, tdist)
     else:
         plan.complete_rows(rank, slab, mirrors, tdist)
         torch.cuda.synchronize(dev)
         del mirrors
-        rows = slab.cpu().numpy()
+    step = max(1, (256 << 20) // max(1, n * slab.element_size()))     # rows per host copy: the slab never sits on the host whole
+
+    def row_chunks():
+        for a in range(0, hi - lo, step):
+            yield a, slab[a:min(hi - lo, a + step)].cpu().numpy()
+
     if params.out_freq_file and rank == 0:
         print("Writing frequency matrix")
         api.write_mat_text(params.out_freq_file, ctx.frequencies(counts, totals).cpu().numpy())
@@ -299,17 +304,21 @@ def main_distributed(params):
         tdist.barrier()
         fd = os.open(params.out_file, os.O_RDWR)
         try:
-            flat, done = memoryview(np.ascontiguousarray(rows, dtype=np.float32).reshape(-1)).cast("B"), 0
-            while done < len(flat):
-                done += os.pwrite(fd, flat[done:done + (1 << 30)], lo * n * 4 + done)
+            for a, rows in row_chunks():
+                flat, done = memoryview(np.ascontiguousarray(rows, dtype=np.float32).reshape(-1)).cast("B"), 0
+                while done < len(flat):
+                    done += os.pwrite(fd, flat[done:], (lo + a) * n * 4 + done)
         finally:
             os.close(fd)
         tdist.barrier()
     else:
         say("Writing distance matrix")
         for r in range(world):                                  # rank order = row order
-            if r == rank and (hi > lo or r == 0):
-                api.write_mat_text(params.out_file, rows.reshape(hi - lo, n), append=r > 0)
+            if r == rank:
+                if r == 0 and hi == lo:
+                    api.write_mat_text(params.out_file, np.zeros((0, n)))
+                for a, rows in row_chunks():
+                    api.write_mat_text(params.out_file, rows, append=(r > 0 or a > 0))
             tdist.barrier()
     tdist.destroy_process_group()
     return 0
