@@ -280,6 +280,39 @@ def main_distributed(params):
     slab, mirrors = plan.allocate(rank, dev, dtype)
     plan.compute(ctx, counts, totals, params.dist, rank, slab, mirrors)
     torch.cuda.synchronize(dev)
+    if params.large == "memmap":
+        # The float32 container needs no second exchange: every rank writes exactly the entries it evaluated - its blocks
+        # and their transposes - into their byte ranges of the file (disjoint between ranks by construction of the plan).
+        if params.out_freq_file and rank == 0:
+            print("Writing frequency matrix")
+            api.write_mat_text(params.out_freq_file, ctx.frequencies(counts, totals).cpu().numpy())
+        if rank == 0:
+            with open(params.out_file, "wb") as f:
+                f.truncate(n * n * 4)
+        tdist.barrier()
+        fd = os.open(params.out_file, os.O_RDWR)
+
+        def put_block(t, row0, col0):                           # t[R, C] on the device -> rows row0.., columns col0..
+            per = max(1, (256 << 20) // max(1, t.shape[1] * 4))
+            for a in range(0, t.shape[0], per):
+                h = t[a:a + per].contiguous().cpu().numpy()
+                flat, width = memoryview(h.reshape(-1)).cast("B"), h.shape[1] * 4
+                for r in range(h.shape[0]):
+                    piece, at, done = flat[r * width:(r + 1) * width], ((row0 + a + r) * n + col0) * 4, 0
+                    while done < width:
+                        done += os.pwrite(fd, piece[done:], at + done)
+
+        try:
+            for ((r0, r1), (c0, c1), kind, peer), m in zip(plan.work(rank), mirrors):
+                put_block(slab[r0 - lo:r1 - lo, c0:c1], r0, c0)
+                if m is not None:
+                    put_block(m, c0, r0)
+        finally:
+            os.close(fd)
+        tdist.barrier()
+        tdist.destroy_process_group()
+        return 0
+    # text matrix: rows have to be complete - the transposed blocks go to the ranks whose rows they belong to
     if rehearsal:                                               # gloo moves host tensors
         slab_h, mirrors_h = slab.cpu(), [None if m is None else m.cpu() for m in mirrors]
         del slab, mirrors
@@ -297,29 +330,14 @@ def main_distributed(params):
     if params.out_freq_file and rank == 0:
         print("Writing frequency matrix")
         api.write_mat_text(params.out_freq_file, ctx.frequencies(counts, totals).cpu().numpy())
-    if params.large == "memmap":
-        if rank == 0:
-            with open(params.out_file, "wb") as f:
-                f.truncate(n * n * 4)
-        tdist.barrier()
-        fd = os.open(params.out_file, os.O_RDWR)
-        try:
+    say("Writing distance matrix")
+    for r in range(world):                                      # rank order = row order
+        if r == rank:
+            if r == 0 and hi == lo:
+                api.write_mat_text(params.out_file, np.zeros((0, n)))
             for a, rows in row_chunks():
-                flat, done = memoryview(np.ascontiguousarray(rows, dtype=np.float32).reshape(-1)).cast("B"), 0
-                while done < len(flat):
-                    done += os.pwrite(fd, flat[done:], (lo + a) * n * 4 + done)
-        finally:
-            os.close(fd)
+                api.write_mat_text(params.out_file, rows, append=(r > 0 or a > 0))
         tdist.barrier()
-    else:
-        say("Writing distance matrix")
-        for r in range(world):                                  # rank order = row order
-            if r == rank:
-                if r == 0 and hi == lo:
-                    api.write_mat_text(params.out_file, np.zeros((0, n)))
-                for a, rows in row_chunks():
-                    api.write_mat_text(params.out_file, rows, append=(r > 0 or a > 0))
-            tdist.barrier()
     tdist.destroy_process_group()
     return 0
 
