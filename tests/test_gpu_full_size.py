@@ -71,3 +71,29 @@ def test_full_size_matrix_properties(ctx, config, pattern, metric, seed, lo, hi)
     assert torch.allclose(rs, cs, rtol=1e-12)
     del out
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("metric,diag,lo,hi", [("KT", 1.0, -1.0, 1.0), ("SC", 0.0, 0.0, 2.0)])
+def test_full_size_rank_metrics(ctx, metric, diag, lo, hi):
+    """Kendall (matrix-core Gram over the materialised pair-sign operand, reverse-complement folded) and Spearman (exact
+    int8 Gram on doubled ranks) at the C2 size: symmetry, diagonal, range, row blocks off the tile grid, the unfolded /
+    int8 operand variants bit for bit, and two rows against the SciPy-pinned oracle on 3 000 columns each."""
+    import torch
+    counts, totals = profiles(ctx, "1111", 50001)
+    out = torch.empty((N, N), dtype=torch.float64, device="cuda")
+    _, st = ctx.pairwise(counts, totals, metric, out=out, want_stats=True)
+    assert st["pairs"] == N * N // 2
+    assert is_symmetric(out)
+    assert bool((torch.diagonal(out) == diag).all())
+    assert float(out.min()) >= lo - 1e-12 and float(out.max()) <= hi + 1e-12 and not bool(torch.isnan(out).any())
+    assert torch.equal(ctx.pairwise(counts, totals, metric, row_begin=40_001, row_end=40_260), out[40_001:40_260])
+    if metric == "KT":
+        assert st["kernel_id"] == 8 and st["rc_folded"]
+        assert torch.equal(ctx.pairwise(counts, totals, "KT", row_begin=130, row_end=390, rc_fold=False), out[130:390])
+        assert torch.equal(ctx.pairwise(counts, totals, "KT", row_begin=130, row_end=390, pairdot_i8=True), out[130:390])
+    freq = oracle.counts_to_frequencies(counts.cpu().numpy().astype(np.int64), totals.cpu().numpy())
+    for r, c0 in ((0, 20_000), (N - 1, 0)):
+        want = oracle.pairwise_block(np.vstack([freq[r:r + 1], freq[c0:c0 + 3000]]), metric, 0, 1)[0, 1:]
+        np.testing.assert_allclose(out[r, c0:c0 + 3000].cpu().numpy(), want, rtol=1e-6, atol=1e-12)
+    del out
+    torch.cuda.empty_cache()
