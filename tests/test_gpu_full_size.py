@@ -97,3 +97,30 @@ def test_full_size_rank_metrics(ctx, metric, diag, lo, hi):
         np.testing.assert_allclose(out[r, c0:c0 + 3000].cpu().numpy(), want, rtol=1e-6, atol=1e-12)
     del out
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("pattern,strand,seed", [("1111", "both", 50001), ("11011011", "both", 50005), ("1111", "plus", 50001),
+                                                  ("1101", "both", 50001), ("111111", "minus", 50001)])
+def test_full_size_profiles(ctx, pattern, strand, seed):
+    """Stage 1 on the whole 50 000-contig assembly (fast path for the forward-word cases, general path for the others):
+    row sums are the totals, the totals are the window counts the reference's arithmetic gives, '-s both' profiles are
+    reverse-complement symmetric, and 150 contigs drawn over the whole range equal the oracle bit for bit."""
+    import torch
+    seq, off = synthetic.contig_bytes(N, 2000, seed=seed)
+    counts, totals = ctx.count_profiles(torch.from_numpy(seq.copy()).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), pattern, strand)
+    W, k = len(pattern), pattern.count("1")
+    per_strand = 2000 - W + 1
+    want_total = 2 * per_strand + W - 1 if strand == "both" else per_strand
+    assert int(totals.min()) == int(totals.max()) == want_total
+    assert torch.equal(counts.sum(dim=1, dtype=torch.int64), totals.to(torch.int64))
+    if strand == "both":                                        # seq + revcomp(seq) is its own reverse complement: word w <-> rc(w)
+        d = torch.arange(4 ** k, device="cuda")
+        digits = torch.stack([(d >> (2 * (k - 1 - i))) & 3 for i in range(k)], dim=1)      # C0 G1 A2 T3, first base first
+        rc = ((digits.flip(1) ^ 1) << (2 * (k - 1 - torch.arange(k, device="cuda")))).sum(dim=1)
+        if pattern == pattern[::-1]:
+            assert torch.equal(counts, counts[:, rc])
+    rng = np.random.default_rng(seed)
+    pick = np.sort(rng.choice(N, size=150, replace=False))
+    recs = [seq[int(off[i]):int(off[i + 1])].tobytes() for i in pick]
+    oc, ot = oracle.compute_counts(recs, pattern, strand)
+    assert np.array_equal(counts[torch.from_numpy(pick).cuda()].cpu().numpy().astype(np.int64), oc)
