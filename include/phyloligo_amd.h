@@ -122,6 +122,10 @@ void po_ctx_destroy(po_ctx* ctx);
 int po_ctx_set_stream(po_ctx* ctx, void* hip_stream);   /* hipStream_t of the caller; NULL = default */
 int po_ctx_synchronize(po_ctx* ctx);
 int po_ctx_device_name(po_ctx* ctx, char* buf, size_t len);
+/* Frees every device workspace the context has grown (operand matrices, the materialised Kendall / Bray-Curtis
+ * operand of up to 24 GB, staging of the host-pointer forms); the next call allocates again.  The reference's
+ * workers hold nothing between calls (joblib processes, bin/phyloligo.py:386-390): this is the way back to that. */
+int po_ctx_trim(po_ctx* ctx);
 
 /* ---- pattern ---------------------------------------------------------------------------- *
  * `pattern` is the -p string of '1'/'0' (bin/phyloligo.py:1027); -k N is "1"*N (:1040-1041).

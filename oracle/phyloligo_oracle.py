@@ -13,6 +13,19 @@ bit-exact or <=1e-15).  KT and SC cannot be produced by the reference here (KT n
 Biopython's compiled Bio.Cluster, SC raises NameError in the reference as shipped):
 those two are pinned against SciPy (kendalltau variant 'b', spearmanr) and labelled so.
 
+What stays dependent on stand-ins for Biopython (absent here), exactly:
+  * parse_fasta below restates SimpleFastaParser from Biopython's published behaviour; no
+    reference run can pin it.  Everything DOWNSTREAM of the parser is pinned: the records of
+    every hand-built FASTA case (tests/fasta_cases.py) went through the reference's own
+    select_strand / cut_sequence_and_count_pattern / compute_frequency
+    (tests/golden/fasta_cases.npz, checked by test_fasta_cases_downstream_of_the_parser);
+  * Seq.reverse_complement on the 'minus' / 'both' strands: A/C/G/T/N of either case are
+    complemented by the stand-in exactly as Biopython does.  IUPAC ambiguity codes
+    (RYKMSWBDHV), gaps, digits and any other byte are not A/C/G/T before or after any
+    complement table, so they split words identically (stand-in independent).  The ONE
+    dependent character is 'U' / 'u': here a separator on both strands; a Biopython release
+    whose DNA table maps U -> A would count the minus-strand copy of a U as 'A'.
+
 Reference lines restated (paths relative to /root/reference/phylopackage/):
   bin/phyloligo.py:124-149   select_strand
   bin/phyloligo.py:601-631   cut_sequence_and_count_pattern

@@ -58,6 +58,7 @@ SIGNATURES = {
     "po_ctx_set_stream": (_int, [_vp, _vp]),
     "po_ctx_synchronize": (_int, [_vp]),
     "po_ctx_device_name": (_int, [_vp, _c.c_char_p, _c.c_size_t]),
+    "po_ctx_trim": (_int, [_vp]),
     "po_pattern_info": (_int, [_cp, _c.POINTER(_u32), _c.POINTER(_u32), _c.POINTER(_u64)]),
     "po_count_profiles": (_int, [_vp, _vp, _vp, _u64, _cp, _int, _vp, _vp]),
     "po_count_profiles_dev": (_int, [_vp, _vp, _vp, _u64, _u64, _cp, _int, _vp, _vp]),

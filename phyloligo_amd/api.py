@@ -72,6 +72,10 @@ class Context:
     def synchronize(self):
         check(self._lib.po_ctx_synchronize(self._h))
 
+    def trim(self):
+        """free the device workspaces this context has grown (po_ctx_trim); the next call allocates again"""
+        check(self._lib.po_ctx_trim(self._h))
+
     def _use_torch_stream(self):
         import torch
         check(self._lib.po_ctx_set_stream(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))

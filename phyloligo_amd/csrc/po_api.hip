@@ -3,6 +3,7 @@
 #include "po_internal.h"
 
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -104,6 +105,20 @@ extern "C" void po_ctx_destroy(po_ctx* ctx) {
     delete ctx;
 }
 
+extern "C" int po_ctx_trim(po_ctx* ctx) {
+    PO_REQUIRE(ctx != nullptr, "po_ctx_trim: ctx is NULL");
+    PO_HIP(hipSetDevice(ctx->device));
+    PO_HIP(hipStreamSynchronize(ctx->stream));
+    po_buf* all[] = {&ctx->ws_freq, &ctx->ws_rowstat, &ctx->ws_aux, &ctx->ws_io, &ctx->ws_fold, &ctx->ws_fold_src, &ctx->ws_recover,
+                     &ctx->ws_pairdot, &ctx->ws_pq, &ctx->ws_thermo, &ctx->ws_fasta};
+    for (po_buf* b : all) buf_free(b);
+    ctx->pq_key = ~0ull;                    // cached tables went with their buffers
+    ctx->fold_dim = ctx->fold_gran = ctx->fold_dim_f = ctx->fold_dbl_at = 0;
+    ctx->fasta_data = nullptr;
+    ctx->fasta_len = ctx->fasta_records = ctx->fasta_seq_bytes = 0;
+    return PO_OK;
+}
+
 extern "C" int po_ctx_set_stream(po_ctx* ctx, void* hip_stream) {
     PO_REQUIRE(ctx != nullptr, "po_ctx_set_stream: ctx is NULL");
     ctx->stream = static_cast<hipStream_t>(hip_stream);
@@ -139,21 +154,26 @@ int po_buf_reserve(po_ctx* ctx, po_buf* b, size_t bytes) {
     return PO_OK;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel function of the process (per device), not to a
+// context: two contexts on one device must see one table, or the second one could lower a limit the first relies on.
+// The granted size only ever grows.
+namespace {
+struct shmem_entry { int device; const void* func; size_t bytes; };
+std::mutex g_shmem_mu;
+std::vector<shmem_entry> g_shmem;
+}
+
 int po_func_shmem(po_ctx* ctx, const void* func, size_t bytes) {
-    for (int i = 0; i < ctx->n_shmem_set; ++i)
-        if (ctx->shmem_set[i].func == func) {
-            if (ctx->shmem_set[i].bytes >= bytes) return PO_OK;
+    std::lock_guard<std::mutex> lock(g_shmem_mu);
+    for (auto& e : g_shmem)
+        if (e.device == ctx->device && e.func == func) {
+            if (e.bytes >= bytes) return PO_OK;
             PO_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-            ctx->shmem_set[i].bytes = bytes;
+            e.bytes = bytes;
             return PO_OK;
         }
     PO_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    const int cap = (int)(sizeof(ctx->shmem_set) / sizeof(ctx->shmem_set[0]));
-    if (ctx->n_shmem_set < cap) {          // a full table only costs the repeated attribute call
-        ctx->shmem_set[ctx->n_shmem_set].func = func;
-        ctx->shmem_set[ctx->n_shmem_set].bytes = bytes;
-        ++ctx->n_shmem_set;
-    }
+    g_shmem.push_back({ctx->device, func, bytes});
     return PO_OK;
 }
 
@@ -433,6 +453,22 @@ static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
             rc = po_buf_reserve(ctx, &ctx->ws_freq, kt_ws);
             if (rc) return rc;
         }
+        // the materialised pair-sign operand: sized for the reverse-complement folded layout when the word space is 4^k
+        // (what `-s both` gives), else for all words; a call that needs more grows it lazily
+        if (po_kt_pairdot_supported(dim)) {
+            const uint32_t selfs = po_fold_selfs(dim);
+            const bool fold = selfs != 0xFFFFFFFFu;
+            const size_t opb = po_kt_pairdot_operand_bytes(n, dim, fold ? selfs + (dim - selfs) / 2 : dim, fold ? selfs : 0, fold, 1);
+            if (opb <= PO_PAIRDOT_MAX_OPERAND) {
+                rc = po_buf_reserve(ctx, &ctx->ws_pairdot, opb);
+                if (rc) return rc;
+            }
+        }
+    }
+    // the pair-dot operand of an earlier Kendall / Bray-Curtis call (up to 24 GB) is dead weight for the other metrics
+    if (metric != PO_KT && metric != PO_BC && ctx->ws_pairdot.cap > (1ull << 30)) {
+        PO_HIP(hipStreamSynchronize(ctx->stream));
+        buf_free(&ctx->ws_pairdot);
     }
     if (metric == PO_JSD) {
         rc = po_logtab_init(ctx);

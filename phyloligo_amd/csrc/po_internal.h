@@ -69,15 +69,12 @@ struct po_ctx {
     uint32_t* h_flag = nullptr;        // pinned host word for the fold decision
     void* h_stage[2] = {nullptr, nullptr};   // pinned staging buffers of the host-pointer entry points (device -> host rows)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    // kernels whose dynamic-LDS limit has been raised, with the size granted (po_func_shmem)
-    struct { const void* func; size_t bytes; } shmem_set[96];
-    int n_shmem_set = 0;
 };
 
 int po_buf_reserve(po_ctx* ctx, po_buf* b, size_t bytes);
 unsigned po_host_threads(unsigned cap);   // usable CPUs (affinity, cgroup quota), at most cap (po_io.cpp)
-// hipFuncAttributeMaxDynamicSharedMemorySize for `func`, raised once per context (and again only if a later
-// launch asks for more): the attribute call is host work that does not belong in a launch path
+// hipFuncAttributeMaxDynamicSharedMemorySize for `func`, raised once per process and device (and again only if a
+// later launch asks for more; it never goes down): the attribute call is host work that does not belong in a launch path
 int po_func_shmem(po_ctx* ctx, const void* func, size_t bytes);
 #define PO_SHMEM(ctx, kernel, bytes)                                                       \
     do {                                                                                   \

@@ -609,6 +609,7 @@ int po_launch_bc_thermo_prep(po_ctx* ctx, const uint32_t* p8t, uint32_t groups_p
     *eligible = false;
     const uint32_t epc = fmt_fp4 ? 32u : 16u, per_stage = epc * SCH;
     const uint32_t words = groups_pad * 4;                 // padded word columns are all zero: no planes
+    if (words >= (1u << 20)) return PO_OK;                 // emap packs the word index into 20 bits (bc_emap_kernel)
     const uint64_t op_n = po_round_up(n, TE);
     // ws_thermo: header | colmax[words] | off[words] | rowsum[op_n] | emap[...]
     const size_t b_hdr = 256, b_cm = po_round_up((size_t)words * 4, 256), b_off = b_cm, b_rs = po_round_up(op_n * sizeof(double), 256);
@@ -632,7 +633,10 @@ int po_launch_bc_thermo_prep(po_ctx* ctx, const uint32_t* p8t, uint32_t groups_p
     // worth it while a word owns few planes (the matrix cores do ~27 FP4 planes in the time the SAD kernel does one
     // word), and bounded in memory
     const uint64_t op_bytes = kpad / epc * op_n * 16;
-    if (!h.ok || h.k_stages == 0 || kpad > (uint64_t)(fmt_fp4 ? 24 : 12) * dim || op_bytes > (24ull << 30)) return PO_OK;
+    if (!h.ok || h.k_stages == 0 || kpad > (uint64_t)(fmt_fp4 ? 24 : 12) * dim || op_bytes > PO_PAIRDOT_MAX_OPERAND) return PO_OK;
+    // float32 sums of FP4 products are exact below 2^24: sum_w min(ca_w, cb_w) <= n (doubling included).  Counts <= 255 and
+    // 4^8 words keep n below that, a recovered matrix of arbitrary width need not
+    if (fmt_fp4 && h.ntot >= (1ull << 24)) return PO_OK;
     // emap lives behind the row sums; the buffer may move when it grows, so re-derive the pointers afterwards
     rc = po_buf_reserve(ctx, &ctx->ws_pairdot, op_bytes + kpad * sizeof(uint32_t) + 256);
     if (rc) return rc;

@@ -15,9 +15,17 @@ are the reference's code, executed unmodified:
     ref.compute_distances_joblib (Eucl, JSD, BC), phylodist.Eucl/JSD/KL, numpy.savetxt.
 
 Only numbers (inputs and the reference's outputs) are stored.  The stand-in `Seq` class
-complements A/C/G/T/N in both cases and leaves every other symbol unchanged, so 'minus'
-and 'both' vectors for IUPAC letters are pinned only "modulo the stand-in" (they stay
-non-ACGT either way).  KT and SC vectors come from SciPy and are labelled `scipy_`.
+complements A/C/G/T/N in both cases and leaves every other symbol unchanged.  What that
+leaves stand-in dependent on the 'minus' / 'both' strands is exactly ONE character class:
+  * IUPAC ambiguity codes (RYKMSWBDHVN, any case): Biopython maps them to ambiguity codes,
+    the stand-in leaves them as they are -- not A/C/G/T either way, so the split on
+    [^ACGT]+ (bin/phyloligo.py:625) gives the same words: stand-in INDEPENDENT;
+  * gaps, digits, '*', '.', any other byte: unchanged by both: stand-in INDEPENDENT;
+  * 'U' / 'u': the stand-in leaves it (a separator on both strands); Biopython's DNA
+    complement table maps U -> A (releases that do not raise on mixed T/U), which would
+    make the minus-strand copy of a U countable as 'A': stand-in DEPENDENT, unpinned.
+    (The plus strand is pinned: 'U' is not in ACGT, bin/phyloligo.py:625.)
+KT and SC vectors come from SciPy and are labelled `scipy_`.
 """
 import importlib.util
 import io
@@ -195,6 +203,35 @@ def main():
         cli[name] = np.array([" ".join(argv), str(pat), params.strand, params.dist, params.out_file, params.large,
                               str(params.threads_max)], dtype="U")
     np.savez_compressed(os.path.join(HERE, "cli.npz"), **cli)
+    # (5) FASTA cases: everything DOWNSTREAM of SeqIO.parse is the reference's own code.  Bio.SeqIO is absent here, so
+    # the records come from the oracle's restated parser (oracle.parse_fasta: that restatement stays unpinned); every
+    # parsed string then goes through ref.select_strand / cut_sequence_and_count_pattern / compute_frequency unmodified.
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import phyloligo_oracle as oracle
+    from tests.fasta_cases import CASES, PROFILE_KEYS
+    fa = {}
+    for name, data in sorted(CASES.items()):
+        titles, seqs = oracle.parse_fasta(data)
+        fa["data_" + name] = np.frombuffer(data, dtype=np.uint8)
+        fa["titles_" + name] = np.array([t.encode("latin-1") for t in titles], dtype="S") if titles else np.zeros(0, dtype="S1")
+        fa["seqs_" + name] = np.array(seqs, dtype="S") if any(seqs) else np.array([b""] * len(seqs), dtype="S1")
+        fa["seqlens_" + name] = np.array([len(x) for x in seqs], dtype=np.int64)
+        for pat, strand in PROFILE_KEYS:
+            k = pat.count("1")
+            words = ["".join(w) for w in ref.product(("C", "G", "A", "T"), repeat=k)]
+            counts = np.zeros((len(seqs), 4 ** k), dtype=np.int64)
+            totals = np.zeros(len(seqs), dtype=np.int64)
+            freqs = np.zeros((len(seqs), 4 ** k), dtype=np.float64)
+            for i, sq in enumerate(seqs):
+                text = sq.decode("latin-1")
+                cw, tot = ref.cut_sequence_and_count_pattern(ref.select_strand(text, strand).upper(), pat)
+                counts[i] = [cw.get(w, 0) for w in words]
+                totals[i] = tot
+                freqs[i] = ref.compute_frequency(text, pat, strand)
+            fa["counts_%s_%s_%s" % (name, pat, strand)] = counts
+            fa["totals_%s_%s_%s" % (name, pat, strand)] = totals
+            fa["freq_%s_%s_%s" % (name, pat, strand)] = freqs
+    np.savez_compressed(os.path.join(HERE, "fasta_cases.npz"), **fa)
     print("golden vectors written to", HERE)
 
 

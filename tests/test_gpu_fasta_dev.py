@@ -1,8 +1,17 @@
-"""FASTA ingest on the device (po_fasta_scan_dev / po_fasta_extract_dev) against the host parser of the same library
-(po_fasta_scan / po_fasta_extract, Biopython SimpleFastaParser semantics restated in csrc/po_io.cpp): sequence bytes,
-record offsets and titles must be identical for every input, across the 4 KiB blocks the kernels cut the file into."""
+"""FASTA ingest on the device (po_fasta_scan_dev / po_fasta_extract_dev) against the ORACLE's parser
+(oracle.parse_fasta: Biopython SimpleFastaParser semantics as Bio.SeqIO.parse yields them at bin/phyloligo.py:869) and,
+as a second witness, the host parser of the library (po_fasta_scan / po_fasta_extract, csrc/po_io.cpp): titles, sequence
+bytes and record offsets must be identical for every input, across the 4 KiB blocks the kernels cut the file into.
+What the reference computes downstream of the parser for the hand-built cases (its own select_strand /
+cut_sequence_and_count_pattern / compute_frequency, run by tests/golden/make_golden.py) is held against the device path
+in test_reference_profiles_of_the_parsed_cases."""
+import os
+
 import numpy as np
 import pytest
+
+from oracle import phyloligo_oracle as oracle
+from tests.fasta_cases import CASES, PROFILE_KEYS
 
 pytestmark = pytest.mark.gpu
 
@@ -19,33 +28,49 @@ def both(ctx, tmp_path, data, name="x.fa"):
     import phyloligo_amd as pa
     path = tmp_path / name
     path.write_bytes(data)
-    want_seq, want_off, want_titles = pa.fasta_index(np.frombuffer(data, dtype=np.uint8)) if data else (np.zeros(0, np.uint8), np.zeros(1, np.uint64), [])
     seq, off, titles = pa.api.fasta_index_dev(ctx, str(path))
-    assert np.array_equal(seq.cpu().numpy(), want_seq)
-    assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+    got_seq, got_off = seq.cpu().numpy(), off.cpu().numpy().astype(np.uint64)
+    # (1) the oracle: titles, joined sequence bytes, offsets
+    o_titles, o_seqs = oracle.parse_fasta(data)
+    assert list(titles) == o_titles
+    assert len(got_off) == len(o_seqs) + 1 and got_off[0] == 0
+    assert np.array_equal(got_off[1:], np.cumsum([len(x) for x in o_seqs], dtype=np.uint64))
+    assert got_seq.tobytes() == b"".join(o_seqs)
+    # (2) the library's host parser
+    want_seq, want_off, want_titles = pa.fasta_index(np.frombuffer(data, dtype=np.uint8)) if data else (np.zeros(0, np.uint8), np.zeros(1, np.uint64), [])
+    assert np.array_equal(got_seq, want_seq)
+    assert np.array_equal(got_off, want_off)
     assert list(titles) == list(want_titles)
     return seq, off, titles
-
-
-CASES = {
-    "plain": b">a one\nACGT\nAC\n>b\nGGGG\n",
-    "crlf": b">a one \r\nACGT\r\nAC\r\n>b\t tab title \r\nGG GG\r\n",
-    "no_final_newline": b">a\nACGT\n>b\nTT",
-    "header_at_eof": b">a\nACGT\n>b",
-    "header_at_eof_nl": b">a\nACGT\n>b\n",
-    "empty_records": b">a\n>b\n\n>c\nAC\n\n\n>d\n",
-    "leading_blank": b"\n  \n\r\n>a\nAC\n",
-    "inner_gt": b">a\nAC>GT\nA>\n>b\nTT\n",
-    "spaces_inside": b">a\nA C G T\n  ACGT  \n",
-    "lowercase_n": b">a\nacgtnNNNNacgt\n",
-    "only_blank": b"\n\n  \n",
-    "single_byte_lines": b">a\nA\nC\nG\nT\n",
-}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_hand_built_cases(ctx, tmp_path, name):
     both(ctx, tmp_path, CASES[name])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_profiles_of_the_parsed_cases(ctx, tmp_path, golden_dir, name):
+    """file bytes -> device parser -> count_kernel  ==  the reference's own counting code run on the records
+    (tests/golden/fasta_cases.npz: IUPAC codes, U, gaps, digits, lower case, CRLF, empty records)"""
+    g = np.load(os.path.join(golden_dir, "fasta_cases.npz"))
+    data = CASES[name]
+    assert g["data_" + name].tobytes() == data
+    path = tmp_path / "g.fa"
+    path.write_bytes(data)
+    import phyloligo_amd as pa
+    seq, off, titles = pa.api.fasta_index_dev(ctx, str(path))
+    assert [t.encode("latin-1") for t in titles] == [bytes(t) for t in g["titles_" + name]]
+    assert np.array_equal(np.diff(off.cpu().numpy()), g["seqlens_" + name])
+    for pat, strand in PROFILE_KEYS:
+        want_c, want_t = g["counts_%s_%s_%s" % (name, pat, strand)], g["totals_%s_%s_%s" % (name, pat, strand)]
+        if want_c.shape[0] == 0:
+            continue
+        counts, totals = ctx.count_profiles(seq, off, pat, strand)
+        assert np.array_equal(counts.cpu().numpy().astype(np.int64), want_c), (name, pat, strand)
+        assert np.array_equal(totals.cpu().numpy(), want_t)
+        freq = ctx.frequencies(counts, totals).cpu().numpy()
+        assert np.array_equal(freq, g["freq_%s_%s_%s" % (name, pat, strand)])       # count2freq, bit for bit
 
 
 def test_long_lines_and_many_records_cross_blocks(ctx, tmp_path):
@@ -67,7 +92,7 @@ def test_long_lines_and_many_records_cross_blocks(ctx, tmp_path):
     assert len(titles) == 300 and titles[0].startswith("rec0 some")
 
 
-def test_fuzz_against_host_parser(ctx, tmp_path):
+def test_fuzz_against_oracle_and_host_parser(ctx, tmp_path):
     rng = np.random.default_rng(7)
     alphabet = np.frombuffer(b"ACGTNacgtn>  \r", dtype=np.uint8)
     for case in range(120):

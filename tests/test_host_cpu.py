@@ -58,6 +58,11 @@ FASTA_CASES = [
 ]
 
 
+from tests.fasta_cases import CASES as SHARED_FASTA_CASES
+
+FASTA_CASES = FASTA_CASES + [SHARED_FASTA_CASES[k] for k in sorted(SHARED_FASTA_CASES)]
+
+
 @pytest.mark.parametrize("data", FASTA_CASES)
 def test_fasta_index_matches_biopython_semantics(data):
     titles, seqs = po.parse_fasta(data)

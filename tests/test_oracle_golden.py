@@ -131,3 +131,21 @@ def test_fasta_parser():
     assert seqs == [b"ACGTACGT", b"", b"NNacgt"]
     with pytest.raises(ValueError):
         po.parse_fasta(b"ACGT\n>a\nAC\n")
+
+
+def test_fasta_cases_downstream_of_the_parser(golden_dir):
+    """tests/golden/fasta_cases.npz: the reference's own counting code on the records of every hand-built FASTA case
+    (IUPAC codes, U, gaps, digits, lower case); the oracle must give the same integers and the same float64 quotients."""
+    from tests.fasta_cases import CASES, PROFILE_KEYS
+    g = np.load(os.path.join(golden_dir, "fasta_cases.npz"))
+    for name, data in CASES.items():
+        assert g["data_" + name].tobytes() == data
+        titles, seqs = po.parse_fasta(data)
+        assert [t.encode("latin-1") for t in titles] == [bytes(t) for t in g["titles_" + name]]
+        assert [len(x) for x in seqs] == list(g["seqlens_" + name])
+        for pat, strand in PROFILE_KEYS:
+            counts, totals = po.compute_counts(seqs, pat, strand)
+            assert np.array_equal(counts, g["counts_%s_%s_%s" % (name, pat, strand)]), (name, pat, strand)
+            assert np.array_equal(totals, g["totals_%s_%s_%s" % (name, pat, strand)])
+            if len(seqs):
+                assert np.array_equal(po.counts_to_frequencies(counts, totals), g["freq_%s_%s_%s" % (name, pat, strand)])
