@@ -211,7 +211,7 @@ def main():
         counts, totals = plan.all_gather_profiles(my_counts.cpu(), my_totals.cpu(), dist)
         counts, totals = counts.to(dev), totals.to(dev)
     else:
-        counts, totals = plan.all_gather_profiles(my_counts, my_totals, dist)
+        counts, totals = plan.all_gather_profiles(my_counts, my_totals, dist, force=dist is not None)
     if dist is not None:
         torch.cuda.synchronize(dev)
         allgather_ms = (time.perf_counter() - t0) * 1e3

@@ -11,6 +11,11 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libphyloligo_amd.so")
+# Experiments only (tools/exp/ab.sh): load a variant build from somewhere else instead of overwriting the product
+# library in place.  The name starts with PO_ so that bench.py records it among config.env_knobs.
+if os.environ.get("PO_LIB_PATH"):
+    LIB_PATH = os.path.abspath(os.environ["PO_LIB_PATH"])
+    sys.stderr.write("phyloligo_amd: PO_LIB_PATH set -- loading the VARIANT library %s\n" % LIB_PATH)
 
 PO_OK, PO_EINVAL, PO_ENODEV, PO_ENOMEM, PO_EHIP, PO_EUNSUPPORTED, PO_EIO = 0, -1, -2, -3, -4, -5, -6
 STRANDS = {"both": 0, "plus": 1, "minus": 2}

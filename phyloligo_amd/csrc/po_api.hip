@@ -1,6 +1,7 @@
 // C ABI of libphyloligo_amd.so (include/phyloligo_amd.h): contexts, argument checking, the
 // host-pointer convenience forms, and the dispatch of a pairwise request onto the tile kernels.
 #include "po_internal.h"
+#include "po_host.h"
 
 #include <atomic>
 #include <mutex>
@@ -822,46 +823,25 @@ static int copy_rows_to_host(po_ctx* ctx, const uint8_t* d_src, size_t src_pitch
         PO_HIP(hipHostMalloc(&ctx->h_stage[0], kStage, hipHostMallocDefault));
         PO_HIP(hipHostMalloc(&ctx->h_stage[1], kStage, hipHostMallocDefault));
     }
-    const uint64_t rows_per = kStage / row_bytes;
-    const uint64_t n_chunks = (rows + rows_per - 1) / rows_per;
-    const unsigned n_thr = po_host_threads(14);
-    auto issue = [&](uint64_t c) -> hipError_t {
-        const uint64_t r0 = c * rows_per, nr = (rows - r0 < rows_per) ? rows - r0 : rows_per;
-        return hipMemcpy2DAsync(ctx->h_stage[c & 1], row_bytes, d_src + r0 * src_pitch, src_pitch, row_bytes, nr,
-                                hipMemcpyDeviceToHost, ctx->stream);
+    // the ring itself is host code (po_ring_copy_rows, po_io.cpp: it also runs under the thread sanitizer, `make san`);
+    // here only the two HIP calls it is built around
+    struct d2h_src { po_ctx* ctx; const uint8_t* d_src; size_t src_pitch, row_bytes; hipError_t err; } u{ctx, d_src, src_pitch, row_bytes, hipSuccess};
+    po_ring_source ring;
+    ring.user = &u;
+    ring.issue = [](void* p, uint64_t, void* stage, uint64_t r0, uint64_t nr) -> int {
+        d2h_src* s = static_cast<d2h_src*>(p);
+        s->err = hipMemcpy2DAsync(stage, s->row_bytes, s->d_src + r0 * s->src_pitch, s->src_pitch, s->row_bytes, nr,
+                                  hipMemcpyDeviceToHost, s->ctx->stream);
+        return s->err == hipSuccess ? PO_OK : PO_EHIP;
     };
-    // The copy threads live for the whole call (spawning 8 threads per 32 MB chunk cost ~20 % of the copy): they wait for
-    // `ready` to pass their chunk, copy their rows of it and count themselves into `done`; the main thread waits for a
-    // chunk's DMA, for the copies of the chunk before it (whose staging buffer the next DMA overwrites), issues the next
-    // DMA and releases the chunk.
-    std::atomic<uint64_t> ready{0}, done{0};
-    std::atomic<bool> failed{false};
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < n_thr; ++t)
-        th.emplace_back([&, t]() {
-            for (uint64_t c = 0; c < n_chunks; ++c) {
-                while (ready.load(std::memory_order_acquire) <= c) {
-                    if (failed.load(std::memory_order_relaxed)) return;
-                    std::this_thread::yield();
-                }
-                const uint64_t r0 = c * rows_per, nr = (rows - r0 < rows_per) ? rows - r0 : rows_per;
-                const uint8_t* src = static_cast<const uint8_t*>(ctx->h_stage[c & 1]);
-                for (uint64_t r = t; r < nr; r += n_thr) memcpy(dst + (r0 + r) * dst_pitch, src + r * row_bytes, row_bytes);
-                done.fetch_add(1, std::memory_order_release);
-            }
-        });
-    hipError_t herr = issue(0);
-    for (uint64_t c = 0; c < n_chunks && herr == hipSuccess; ++c) {
-        herr = hipStreamSynchronize(ctx->stream);                     // chunk c is in its staging buffer
-        if (herr != hipSuccess) break;
-        while (done.load(std::memory_order_acquire) < c * n_thr) std::this_thread::yield();   // chunk c - 1 has left its buffer
-        if (c + 1 < n_chunks) herr = issue(c + 1);                    // next DMA overlaps the host copies of chunk c
-        ready.store(c + 1, std::memory_order_release);
-    }
-    if (herr != hipSuccess) failed.store(true);
-    for (auto& x : th) x.join();
-    if (herr != hipSuccess) { po_set_error("device to host copy: %s", hipGetErrorString(herr)); return PO_EHIP; }
-    return PO_OK;
+    ring.wait = [](void* p) -> int {
+        d2h_src* s = static_cast<d2h_src*>(p);
+        s->err = hipStreamSynchronize(s->ctx->stream);
+        return s->err == hipSuccess ? PO_OK : PO_EHIP;
+    };
+    const int rc = po_ring_copy_rows(ring, ctx->h_stage, kStage, row_bytes, rows, dst, dst_pitch, po_host_threads(14));
+    if (rc == PO_EHIP) po_set_error("device to host copy: %s", hipGetErrorString(u.err));
+    return rc;
 }
 
 // host-pointer forms: stage in ws_io, run the device form, copy the rows back

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "phyloligo_amd.h"
+#include "po_host.h"
 
 // ---- error plumbing --------------------------------------------------------------------
 void po_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
@@ -72,7 +73,6 @@ struct po_ctx {
 };
 
 int po_buf_reserve(po_ctx* ctx, po_buf* b, size_t bytes);
-unsigned po_host_threads(unsigned cap);   // usable CPUs (affinity, cgroup quota), at most cap (po_io.cpp)
 // hipFuncAttributeMaxDynamicSharedMemorySize for `func`, raised once per process and device (and again only if a
 // later launch asks for more; it never goes down): the attribute call is host work that does not belong in a launch path
 int po_func_shmem(po_ctx* ctx, const void* func, size_t bytes);

@@ -39,10 +39,11 @@ class RowBlockPlan:
         return "tournament over %d row block(s), bounds %s" % (self.world, self.bounds if self.world <= 8 else "...")
 
     # ---- the single exchange of the path: exact count matrix to every rank ------------------------
-    def all_gather_profiles(self, my_counts, my_totals, dist):
-        """counts[n, dim] int32 / totals[n] int64 on every rank."""
+    def all_gather_profiles(self, my_counts, my_totals, dist, force=False):
+        """counts[n, dim] int32 / totals[n] int64 on every rank.  force=True issues the collective even in a
+        one-rank group (bench.py's PO_BENCH_FORCE_DIST and the GPU tests: RCCL exercised on a one-GPU box)."""
         import torch
-        if dist is None or self.world == 1:
+        if dist is None or (self.world == 1 and not force):
             return my_counts, my_totals
         dim = my_counts.shape[1]
         counts = torch.empty((self.n, dim), dtype=my_counts.dtype, device=my_counts.device)
