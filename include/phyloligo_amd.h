@@ -46,7 +46,7 @@ typedef enum po_status {
     PO_ENODEV = -2,       /* no usable HIP device */
     PO_ENOMEM = -3,       /* host or device allocation failed */
     PO_EHIP = -4,         /* a HIP runtime call or kernel launch failed */
-    PO_EUNSUPPORTED = -5, /* valid request outside the implemented envelope (window > 32, k > 8) */
+    PO_EUNSUPPORTED = -5, /* valid request outside the implemented envelope (window > 64, k > 8) */
     PO_EIO = -6,          /* file could not be opened / written, malformed FASTA */
 } po_status;
 
@@ -129,7 +129,9 @@ int po_ctx_trim(po_ctx* ctx);
 
 /* ---- pattern ---------------------------------------------------------------------------- *
  * `pattern` is the -p string of '1'/'0' (bin/phyloligo.py:1027); -k N is "1"*N (:1040-1041).
- * window = len(pattern) <= 32, k = number of '1' <= 8, dim = 4^k.                            */
+ * window = len(pattern) <= 64, k = number of '1' <= 8, dim = 4^k.  (The reference takes any length and any k,
+ * bin/phyloligo.py:622-628; 4^9 columns and beyond are impractical anywhere, wider seeds than 64 return
+ * PO_EUNSUPPORTED.)                                                                           */
 int po_pattern_info(const char* pattern, uint32_t* window, uint32_t* k, uint64_t* dim);
 
 /* ---- stage 1: profiles ------------------------------------------------------------------ *

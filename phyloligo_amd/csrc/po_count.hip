@@ -32,17 +32,21 @@ constexpr int kPasses = 1;                         // passes per chunk.  A wave 
                                                    // 115 vs 84 us on 2 kb contigs, 397 vs 349 us on a ragged 0.33 Gb assembly -
                                                    // the serial passes expose the load latency that separate waves overlap.
 constexpr int kChunkSpan = kSpan * kPasses;
-constexpr int kStage = kTile + 64;                 // staged bytes per chunk (halo >= W-1 = 31, multiple of 16 B)
+constexpr int kStage = kTile + 64;                 // staged bytes per chunk (halo >= W-1 = 63 behind the last start at 15 + 2015, multiple of 16 B)
 constexpr uint32_t kMaxLdsBins = 16384;            // 64 KiB histogram; above that count in HBM directly
 
 struct CountParams {
-    uint32_t window, k, dim, nruns, patbits;
+    uint32_t window, k, dim, nruns;
+    uint64_t patbits;      // bit x: window position x is a '1' of the pattern (W <= 64)
     uint32_t sym;          // -s both with a pattern that reads the same in both directions: count the forward words only and
                            // write out hist[w] + hist[rc(w)] (seq + revcomp(seq) is its own reverse complement)
     uint32_t src_shift[PO_MAX_RUNS];
     uint32_t dst_shift[PO_MAX_RUNS];
     uint32_t mask[PO_MAX_RUNS];
     uint32_t le_src[4], le_dst[4];   // the first four runs for a window packed first-base-lowest (fast path)
+    uint32_t two_hist;     // -s both with a pattern that is NOT its own mirror image, fast path available: every wave keeps two
+                           // histograms, forward words of the pattern and forward words of the REVERSED pattern (= the
+                           // minus-strand words relabelled, see the fast path)
     int strand;
     uint32_t n_seqs;
     uint64_t total_bytes;
@@ -208,10 +212,11 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
 }
 
 // ---- counting: one WAVE per chunk, no workgroup barrier -------------------------------------------
-// NARROW: 2 W <= 32, the rolling window registers are 32-bit (every contiguous k-mer up to k = 16).
+// WIDTH: bits of the rolling window registers - 0: 32 (2 W <= 32: every contiguous k-mer up to k = 16), 1: 64 (W <= 32),
+//        2: 128 (W <= 64: spaced seeds wider than 32 positions; two 64-bit halves, generic run loop only).
 // MODE: which rolling registers the slide keeps - 0 forward only (plus strand, or both strands in symmetric mode),
 //       1 reverse only (minus strand), 2 both.
-template <bool LDS_HIST, bool NARROW, int MODE, int RUNS>
+template <bool LDS_HIST, int WIDTH, int MODE, int RUNS>
 __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__ seq,
                                                          const uint64_t* __restrict__ begins,
                                                          const uint64_t* __restrict__ ends,
@@ -228,7 +233,8 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
     // LDS: the histograms of the workgroup's waves first (each aligned to its own size, so that a bin address is an OR),
     // then per wave the staged digits, the byte -> digit table and two slots (junction word, group total)
     constexpr uint32_t kAuxWords = kStage / 4 + 64 + 4;
-    uint32_t* mine = smem + (LDS_HIST ? waves_per_block * P.dim : 0) + wave * kAuxWords;
+    const uint32_t HD = (MODE == 2 && P.two_hist) ? 2u * P.dim : P.dim;      // histogram words per wave
+    uint32_t* mine = smem + (LDS_HIST ? waves_per_block * HD : 0) + wave * kAuxWords;
     uint8_t* codes = reinterpret_cast<uint8_t*>(mine);            // [kStage]
     uint8_t* dtab = reinterpret_cast<uint8_t*>(mine + kStage / 4); // [256] byte -> digit
 
@@ -263,13 +269,13 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
     const int64_t c_hi = min(c_lo + (int64_t)kChunkSpan, L);
     const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)(multi ? wave - min(wave, chunk) : wave));   // first wave of this record in the workgroup
     const bool whole = multi ? (chunk <= wave && wave - chunk + rec_chunks <= waves_per_block) : rec_chunks == 1;
-    uint32_t* hist = smem + (LDS_HIST ? lead * P.dim : 0);         // [dim] when LDS_HIST
-    uint32_t* mid_slot = smem + (LDS_HIST ? waves_per_block * P.dim : 0) + lead * kAuxWords + kStage / 4 + 64;
+    uint32_t* hist = smem + (LDS_HIST ? lead * HD : 0);            // [dim] (or [2][dim]) when LDS_HIST
+    uint32_t* mid_slot = smem + (LDS_HIST ? waves_per_block * HD : 0) + lead * kAuxWords + kStage / 4 + 64;
     // mid_slot[0]: word of the self-mirrored junction window (symmetric mode); mid_slot[1]: words of the group (whole records)
 
     if (LDS_HIST) {
-        uint32_t* own = smem + wave * P.dim;
-        for (uint32_t d = lane * 4; d < P.dim; d += 256) *reinterpret_cast<uint4*>(own + d) = make_uint4(0, 0, 0, 0);
+        uint32_t* own = smem + wave * HD;
+        for (uint32_t d = lane * 4; d < HD; d += 256) *reinterpret_cast<uint4*>(own + d) = make_uint4(0, 0, 0, 0);
     }
     if (lane < 2) mine[kStage / 4 + 64 + lane] = lane == 0 ? 0xFFFFFFFFu : 0u;
     if (multi) __syncthreads();
@@ -283,12 +289,18 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
     const uint32_t W = P.window;
     constexpr bool want_plus = MODE != 1, want_minus = MODE != 0;
     const uint32_t per_word = P.sym ? 2u : 1u;                      // a forward word also stands for its mirror window
-    constexpr bool kFast = LDS_HIST && NARROW && MODE == 0 && RUNS != 0 && kPasses == 1;
+    constexpr bool NARROW = WIDTH == 0;
+    constexpr int kMaxW = WIDTH == 2 ? 64 : 32;                     // widest window of this instantiation
+    constexpr bool kFastT = LDS_HIST && NARROW && RUNS != 0 && kPasses == 1;
+    const bool kFast = kFastT && (MODE != 2 || P.two_hist);
     bool fast_done = false;                                         // wave uniform: this chunk went through the fast path
     // A histogram shared by the chunks of one record is indexed digit-reversed whenever the fast path exists in this
     // kernel (a chunk that has to take the general path then reverses its words one by one); a single-chunk record's
     // histogram is indexed the way its one chunk was counted.
     const bool force_le = kFast && multi && rec_chunks > 1u && (lds_addr(hist) & (P.dim * 4u - 1u)) == 0u;
+    // where a minus-strand word m goes in such a histogram: bin (m with every digit complemented) of the reversed-pattern
+    // histogram - the bin the fast path's relabelled count of the same window lands in (see the write-out)
+    const uint32_t le_cmask = 0x55555555u & (P.dim - 1u), le_rev_base = MODE == 2 ? P.dim : 0u;
     for (int64_t p_lo = c_lo; p_lo < c_hi; p_lo += kSpan) {         // wave uniform; LDS is in order within a wave
     const int64_t p_hi = min(p_lo + (int64_t)kSpan, L);
     const uint64_t a0 = (off + (uint64_t)p_lo) & ~(uint64_t)15;    // 16 B aligned staging origin
@@ -301,6 +313,13 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
     // address as AND-OR onto the aligned histogram base, the start's bit of the lane's validity mask as the addend).
     // The histogram is indexed by the word with its digits reversed (first base lowest), undone when it is written out.
     // Word totals and the junction words come from wave-uniform arithmetic on the record's last W-1 bases.
+    // The minus strand rides on the same register string (SURVEY a-4): the word a window spells on the reverse-complement
+    // strand under pattern P is the forward word under the REVERSED pattern with its digits reversed and complemented,
+    //     minus(P)[w] == plus(reverse(P))[rc(w)],
+    // and the (shift, mask, shift) runs of P for a last-base-lowest window ARE the runs of reverse(P) for a
+    // first-base-lowest one: word_index<RUNS>(win) below is that forward word of reverse(P), digit-reversed.  MODE 1 (-s minus)
+    // counts those alone, MODE 2 (-s both, pattern not its own mirror image) counts both kinds into two histograms; the
+    // write-out relabels: out[d] = H_fwd[digits_reversed(d)] + H_rev[d with every digit complemented].
     const uint32_t hist_addr = lds_addr(hist);
     if (kFast && a0 + kTile <= P.total_bytes && (hist_addr & (P.dim * 4u - 1u)) == 0u) {      // wave uniform
         const uint4 r0 = *reinterpret_cast<const uint4*>(seq + a0 + lane * kPerLane);
@@ -327,7 +346,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
             // starts that count, in staged coordinates: [st_lo, st_hi) (wave uniform), this lane's part as a bit mask
             const int32_t st_lo = (int32_t)(p_lo - pos0);
             const int32_t st_hi = max(st_lo, (int32_t)(min(p_hi, L - (int64_t)W + 1) - pos0));
-            uni_count += (uint32_t)(st_hi - st_lo) * per_word;
+            uni_count += (uint32_t)(st_hi - st_lo) * (MODE == 2 ? 2u : per_word);
             const int32_t s_lo = max(st_lo - (int32_t)(lane * kPerLane), 0);
             const int32_t s_hi = min(st_hi - (int32_t)(lane * kPerLane), (int32_t)kPerLane);
             if (s_hi > s_lo) {
@@ -344,11 +363,13 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
                         lds_add((x & m4) | hbase, (vmask >> sft) & 1u);
                     }
                 } else {
+                    const uint32_t hist2_addr = hist_addr + (MODE == 2 ? P.dim * 4u : 0u);      // reversed-pattern words
 #pragma unroll
                     for (int sft = 0; sft < kPerLane; ++sft) {
                         const uint32_t win = sft == 0 ? plo : sft < 16 ? __builtin_amdgcn_alignbit(phi, plo, 2 * sft)
                                            : sft == 16 ? phi : __builtin_amdgcn_alignbit(halo, phi, 2 * sft - 32);
-                        lds_add(hist_addr + word_index_le<RUNS>(win, P) * 4u, (vmask >> sft) & 1u);
+                        if (MODE != 1) lds_add(hist_addr + word_index_le<RUNS>(win, P) * 4u, (vmask >> sft) & 1u);
+                        if (MODE != 0) lds_add(hist2_addr + word_index<uint32_t, RUNS>(win, P) * 4u, (vmask >> sft) & 1u);
                     }
                 }
             }
@@ -366,10 +387,11 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
                     const uint64_t J = (uint64_t)tail | ((uint64_t)rct << tb);
                     if (lane < W - 1u) {
                         const uint32_t idx = word_index_le<RUNS>((uint32_t)(J >> (2u * lane)), P);
-                        if (2u * lane + 2u < W) lds_add(hist_addr + idx * 4u, 1u);
+                        if (MODE == 2) lds_add(hist_addr + idx * 4u, 1u);                  // no mirror pairing: every junction window
+                        else if (2u * lane + 2u < W) lds_add(hist_addr + idx * 4u, 1u);
                         else if (2u * lane + 2u == W) *mid_slot = digits_reversed(idx, P.k);
                     }
-                    uni_count += 2u * ((W - 1u) >> 1) + ((W & 1u) ? 0u : 1u);
+                    uni_count += MODE == 2 ? W - 1u : 2u * ((W - 1u) >> 1) + ((W & 1u) ? 0u : 1u);
                 } else {                                           // shorter record, or the tail starts before the staged range: general code below
                     *reinterpret_cast<uint4*>(codes + lane * kPerLane) = make_uint4(dg[0], dg[1], dg[2], dg[3]);
                     *reinterpret_cast<uint4*>(codes + lane * kPerLane + 16) = make_uint4(dg[4], dg[5], dg[6], dg[7]);
@@ -429,10 +451,13 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
 
     // ---- slide: lane owns starts [32 lane, 32 lane + 32) ---------------------------------------------
     {
-        typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type reg_t;
-        uint32_t cw[16];
+        typedef typename std::conditional<WIDTH == 0, uint32_t, typename std::conditional<WIDTH == 1, uint64_t, unsigned __int128>::type>::type reg_t;
+        // (windows wider than 32 positions - rare spaced seeds - walk their digits out of LDS in a rolled loop further down:
+        // 95 unrolled steps on two 64-bit halves would triple the code of this translation unit for nothing)
+        constexpr int kCwVecs = WIDTH == 2 ? 0 : (kPerLane + kMaxW - 1 + 15) / 16;      // 16-byte vectors holding the lane's 32 starts + W - 1 more digits
+        uint32_t cw[4 * kCwVecs + 1];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < kCwVecs; ++q) {
             const uint4 v = *reinterpret_cast<const uint4*>(codes + lane * kPerLane + 16 * q);
             cw[4 * q] = v.x; cw[4 * q + 1] = v.y; cw[4 * q + 2] = v.z; cw[4 * q + 3] = v.w;
         }
@@ -446,13 +471,38 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
         // lies inside the record is a word, so the per-position run length and its tests go away - a start s counts iff
         // s_lo <= s < s_hi' with s_hi' cut at the last start whose window ends inside the record.  Half the vector
         // instructions of the general loop below (this kernel is bound by instruction issue, not by bytes).
+        if constexpr (WIDTH == 2) {
+            uint32_t run = 0;
+            const uint8_t* mycodes = codes + lane * kPerLane;
+            for (uint32_t i = 0; i < kPerLane + W - 1; ++i) {
+                const uint32_t d = mycodes[i];
+                run = (d < 4u) ? run + 1u : 0u;
+                if (want_plus) fwd = (fwd << 2) | (reg_t)(d & 3u);
+                if (want_minus) rev = (rev >> 2) | ((reg_t)((d & 3u) ^ 1u) << top);
+                const int s = (int)i - (int)(W - 1);
+                if (s >= s_lo && s < s_hi && run >= W) {
+                    if (want_plus) {
+                        const uint32_t idx = word_index<reg_t, RUNS>(fwd, P);
+                        if (LDS_HIST) atomicAdd(&hist[idx], 1u);
+                        else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
+                        mine_count += per_word;
+                    }
+                    if (want_minus) {
+                        const uint32_t idx = word_index<reg_t, RUNS>(rev, P);
+                        if (LDS_HIST) atomicAdd(&hist[idx], 1u);
+                        else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
+                        ++mine_count;
+                    }
+                }
+            }
+        } else {
         if (!__any((int)(sep_seen != 0u))) {
             const int64_t hi_valid = min(p_hi, L - (int64_t)W + 1) - first;
             const int32_t s_hi2 = (int32_t)max((int64_t)s_lo, min(hi_valid, (int64_t)kPerLane));
             const uint32_t span = (uint32_t)(s_hi2 - s_lo);              // starts of this lane that count
             mine_count += span * ((want_plus ? per_word : 0u) + (want_minus ? 1u : 0u));
 #pragma unroll
-            for (int i = 0; i < kPerLane + PO_MAX_WINDOW - 1; ++i) {
+            for (int i = 0; i < kPerLane + kMaxW - 1; ++i) {
                 if (i < (int)(kPerLane + W - 1)) {                      // uniform
                     const uint32_t d = (cw[i >> 2] >> (8 * (i & 3))) & 3u;
                     if (want_plus) fwd = (fwd << 2) | (reg_t)d;
@@ -466,7 +516,8 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                         }
                         if (want_minus) {
-                            const uint32_t idx = word_index<reg_t, RUNS>(rev, P);
+                            uint32_t idx = word_index<reg_t, RUNS>(rev, P);
+                            if (force_le) idx = (idx ^ le_cmask) + le_rev_base;
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                         }
@@ -476,7 +527,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
         } else {
         uint32_t run = 0;
 #pragma unroll
-        for (int i = 0; i < kPerLane + PO_MAX_WINDOW - 1; ++i) {
+        for (int i = 0; i < kPerLane + kMaxW - 1; ++i) {
             if (i < (int)(kPerLane + W - 1)) {                      // uniform
                 const uint32_t d = (cw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
                 run = (d < 4u) ? run + 1u : 0u;
@@ -493,7 +544,8 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
                             mine_count += per_word;
                         }
                         if (want_minus) {
-                            const uint32_t idx = word_index<reg_t, RUNS>(rev, P);
+                            uint32_t idx = word_index<reg_t, RUNS>(rev, P);
+                            if (force_le) idx = (idx ^ le_cmask) + le_rev_base;
                             if (LDS_HIST) atomicAdd(&hist[idx], 1u);
                             else atomicAdd(&counts[(uint64_t)rec * P.dim + idx], 1u);
                             ++mine_count;
@@ -503,6 +555,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
             }
         }
         }
+        }   // WIDTH != 2
     }
 
     }   // general path
@@ -526,7 +579,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
                                             : base_digit(seq[off + (uint64_t)qpos]);     // short last chunk: before the staged range
                 ok = ok && (d < 4u);
                 if (!fw) d ^= 1u;
-                if ((P.patbits >> x) & 1u) idx = idx * 4u + (d & 3u);
+                if ((P.patbits >> x) & 1ull) idx = idx * 4u + (d & 3u);
             }
             if (ok) {
                 if (P.sym && middle) {
@@ -572,17 +625,23 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
         };
         if (le) {
             // the histogram is indexed by the digit-reversed word: outputs d0..d0+3 differ in their last digit = the first
-            // of the reversed word; the mirror window's word, reversed, is d with every digit complemented: one aligned quad
+            // of the reversed word; the mirror window's word, reversed, is d with every digit complemented: one aligned quad.
+            // The same quad of the reversed-pattern histogram holds the minus-strand counts of d0..d0+3 (MODE 1, 2).
             const uint32_t cmask = 0x55555555u & (P.dim - 1u), top = 2u * P.k - 2u;
+            const uint32_t* hrev = hist + (MODE == 2 ? P.dim : 0u);
             if (whole) {
                 for (uint32_t d0 = lane * 4; d0 < P.dim; d0 += 256) {
                     const uint32_t base = digits_reversed(d0, P.k);
-                    uint32_t v[4];
+                    uint32_t v[4] = {0, 0, 0, 0};
+                    if (MODE != 1) {
 #pragma unroll
-                    for (uint32_t j = 0; j < 4; ++j) v[j] = hist[base + (j << top)];
-                    if (P.sym) {
-                        const uint4 q = *reinterpret_cast<const uint4*>(hist + ((d0 ^ cmask) & ~3u));
+                        for (uint32_t j = 0; j < 4; ++j) v[j] = hist[base + (j << top)];
+                    }
+                    if (P.sym || MODE != 0) {
+                        const uint4 q = *reinterpret_cast<const uint4*>(hrev + ((d0 ^ cmask) & ~3u));
                         v[0] += q.y; v[1] += q.x; v[2] += q.w; v[3] += q.z;
+                    }
+                    if (P.sym) {
 #pragma unroll
                         for (uint32_t j = 0; j < 4; ++j) v[j] += (d0 + j == mid_word) ? 1u : 0u;
                     }
@@ -590,8 +649,9 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
                 }
             } else {                                               // consecutive lanes, consecutive bins: dense atomics
                 for (uint32_t d = lane; d < P.dim; d += 64) {
-                    uint32_t v = hist[digits_reversed(d, P.k)];
-                    if (P.sym) v += hist[d ^ cmask] + (d == mid_word ? 1u : 0u);
+                    uint32_t v = MODE != 1 ? hist[digits_reversed(d, P.k)] : 0u;
+                    if (P.sym || MODE != 0) v += hrev[d ^ cmask];
+                    if (P.sym) v += (d == mid_word ? 1u : 0u);
                     if (v) atomicAdd(&row[d], v);
                 }
             }
@@ -650,22 +710,24 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
         P.le_src[r] = 2 * (pat.window - len) - pat.src_shift[r];    // 2 x (first window position of the run)
         P.le_dst[r] = 2 * (pat.k - len) - pat.dst_shift[r];         // 2 x (rank of its first digit)
     }
-    for (uint32_t i = 0; i < pat.k; ++i) P.patbits |= 1u << pat.ones[i];
+    for (uint32_t i = 0; i < pat.k; ++i) P.patbits |= 1ull << pat.ones[i];
     P.strand = strand;
     bool palindromic = true;
-    for (uint32_t x = 0; x < pat.window; ++x) palindromic = palindromic && (((P.patbits >> x) & 1u) == ((P.patbits >> (pat.window - 1 - x)) & 1u));
+    for (uint32_t x = 0; x < pat.window; ++x) palindromic = palindromic && (((P.patbits >> x) & 1ull) == ((P.patbits >> (pat.window - 1 - x)) & 1ull));
     P.sym = (strand == PO_STRAND_BOTH && palindromic && pat.dim <= kMaxLdsBins) ? 1u : 0u;
     P.n_seqs = (uint32_t)n_seqs;
     P.total_bytes = total_bytes;
 
     const bool lds_hist = pat.dim <= kMaxLdsBins;
-    const size_t per_wave = kStage + 256 + 16 + (lds_hist ? (size_t)pat.dim * 4 : 0);
+    // -s both, pattern not its own mirror image, fast path available (window <= 16, at most 4 runs): two histograms per wave
+    P.two_hist = (strand == PO_STRAND_BOTH && !P.sym && lds_hist && 2 * pat.window <= 32 && pat.nruns <= 4 && pat.dim <= 4096) ? 1u : 0u;
+    const size_t per_wave = kStage + 256 + 16 + (lds_hist ? (size_t)pat.dim * 4 * (P.two_hist ? 2 : 1) : 0);
     uint32_t wpb = (uint32_t)((80u << 10) / per_wave);                // waves per workgroup within 80 KiB of LDS
     wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);                          // up to 4 consecutive chunks of one record share a flush (8 and 16 measured slower)
     const size_t shmem = per_wave * wpb;
     const uint32_t grid = (uint32_t)((max_chunks + wpb - 1) / wpb);
     unsigned long long* tot = reinterpret_cast<unsigned long long*>(d_totals);
-    const bool narrow = 2 * pat.window <= 32;
+    const int width = 2 * pat.window <= 32 ? 0 : (pat.window <= 32 ? 1 : 2);
     const int mode = (strand == PO_STRAND_PLUS || P.sym) ? 0 : (strand == PO_STRAND_MINUS ? 1 : 2);
     auto launch = [&](auto k) -> int {
         PO_SHMEM(ctx, k, shmem);
@@ -675,19 +737,23 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     int lrc = PO_OK;
     // contiguous k-mer: one run that takes the low 2k bits as they are (the reverse register then holds exactly 2W = 2k bits)
     const bool simple = pat.nruns == 1 && pat.src_shift[0] == 0 && pat.dst_shift[0] == 0 && pat.window == pat.k;
-    const int runs = simple ? -1 : (pat.nruns <= 4 ? (int)pat.nruns : 0);
+    const int runs = width == 2 ? 0 : (simple ? -1 : (pat.nruns <= 4 ? (int)pat.nruns : 0));
 #define PO_COUNT_RUNS(L, N, M, R) if (runs == R) lrc = launch(count_kernel<L, N, M, R>);
 #define PO_COUNT_CASE(L, N, M)                                                                                  \
-    if (lds_hist == L && narrow == N && mode == M) {                                                            \
+    if (lds_hist == L && width == N && mode == M) {                                                             \
         PO_COUNT_RUNS(L, N, M, -1) PO_COUNT_RUNS(L, N, M, 0) PO_COUNT_RUNS(L, N, M, 1) PO_COUNT_RUNS(L, N, M, 2) \
         PO_COUNT_RUNS(L, N, M, 3) PO_COUNT_RUNS(L, N, M, 4)                                                      \
     }
-    PO_COUNT_CASE(true, true, 0) PO_COUNT_CASE(true, true, 1) PO_COUNT_CASE(true, true, 2)
-    PO_COUNT_CASE(true, false, 0) PO_COUNT_CASE(true, false, 1) PO_COUNT_CASE(true, false, 2)
-    PO_COUNT_CASE(false, true, 0) PO_COUNT_CASE(false, true, 1) PO_COUNT_CASE(false, true, 2)
-    PO_COUNT_CASE(false, false, 0) PO_COUNT_CASE(false, false, 1) PO_COUNT_CASE(false, false, 2)
+#define PO_COUNT_WIDE(L, M) if (lds_hist == L && width == 2 && mode == M) lrc = launch(count_kernel<L, 2, M, 0>);
+    PO_COUNT_CASE(true, 0, 0) PO_COUNT_CASE(true, 0, 1) PO_COUNT_CASE(true, 0, 2)
+    PO_COUNT_CASE(true, 1, 0) PO_COUNT_CASE(true, 1, 1) PO_COUNT_CASE(true, 1, 2)
+    PO_COUNT_CASE(false, 0, 0) PO_COUNT_CASE(false, 0, 1) PO_COUNT_CASE(false, 0, 2)
+    PO_COUNT_CASE(false, 1, 0) PO_COUNT_CASE(false, 1, 1) PO_COUNT_CASE(false, 1, 2)
+    PO_COUNT_WIDE(true, 0) PO_COUNT_WIDE(true, 1) PO_COUNT_WIDE(true, 2)
+    PO_COUNT_WIDE(false, 0) PO_COUNT_WIDE(false, 1) PO_COUNT_WIDE(false, 2)
 #undef PO_COUNT_RUNS
 #undef PO_COUNT_CASE
+#undef PO_COUNT_WIDE
     if (lrc) return lrc;
     PO_CHECK_LAUNCH("count_kernel");
     return PO_OK;

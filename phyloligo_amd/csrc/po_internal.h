@@ -83,7 +83,7 @@ int po_func_shmem(po_ctx* ctx, const void* func, size_t bytes);
     } while (0)
 
 // ---- pattern ---------------------------------------------------------------------------
-#define PO_MAX_WINDOW 32
+#define PO_MAX_WINDOW 64
 #define PO_MAX_K 8
 #define PO_MAX_RUNS 16
 

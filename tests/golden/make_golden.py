@@ -74,6 +74,8 @@ def load_reference():
 
 PATTERNS = ["1", "11", "1111", "11111", "1101", "10011", "110101", "11011011"]
 STRANDS = ["both", "plus", "minus"]
+# W = 33 (k = 2), W = 41 (k = 4, not a palindrome), W = 64 (k = 6, the widest window the library takes)
+WIDE_PATTERNS = ["1" + "0" * 31 + "1", "1101" + "0" * 36 + "1", "11" + "0" * 30 + "101" + "0" * 27 + "11"]
 
 
 def build_contigs():
@@ -134,6 +136,22 @@ def main():
             store["totals_%s_%s" % (pat, strand)] = totals
             store["freq_%s_%s" % (pat, strand)] = freqs
     np.savez_compressed(os.path.join(HERE, "profiles.npz"), **store)
+
+    # (1b) spaced seeds wider than 32 positions (33..64): same contigs, same reference functions
+    wide = {"contigs": store["contigs"]}
+    for pat in WIDE_PATTERNS:
+        k = pat.count("1")
+        words = ["".join(w) for w in ref.product(("C", "G", "A", "T"), repeat=k)]
+        for strand in STRANDS:
+            counts = np.zeros((len(contigs), 4 ** k), dtype=np.int64)
+            totals = np.zeros(len(contigs), dtype=np.int64)
+            for i, s in enumerate(contigs):
+                cw, tot = ref.cut_sequence_and_count_pattern(ref.select_strand(s, strand).upper(), pat)
+                counts[i] = [cw.get(w, 0) for w in words]
+                totals[i] = tot
+            wide["counts_%s_%s" % (pat, strand)] = counts
+            wide["totals_%s_%s" % (pat, strand)] = totals
+    np.savez_compressed(os.path.join(HERE, "profiles_wide.npz"), **wide)
 
     # (2) distance matrices of a 48-contig set through the reference's joblib driver
     rng = np.random.default_rng(48)

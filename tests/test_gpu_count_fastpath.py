@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 # window <= 16, at most 4 runs, at most 7 ones (LDS histogram); the palindromic ones take the fast path under "both" too
 PATTERNS = ["1", "11", "111", "1111", "11111", "111111", "1111111", "101", "1001", "11011", "1110111", "11011011",
-            "1000000000000001", "1100110011", "110101011", "1101", "10011", "1011101"]
+            "1000000000000001", "1100110011", "110101011", "1101", "10011", "1011101", "1100000000000001", "110100111",
+            "1011", "10110111"]
 LENGTHS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 17, 30, 31, 32, 33, 34, 63, 64, 65, 100, 1999, 2000, 2001, 2013, 2014, 2015,
            2016, 2017, 2018, 2019, 2020, 2030, 2031, 2032, 2033, 2047, 2048, 2049, 4031, 4032, 4033, 4034, 4040, 6047,
            6048, 6049, 6051, 10000]
@@ -51,10 +52,12 @@ def check(ctx, records, pattern, strands=("both", "plus")):
 
 @pytest.mark.parametrize("pattern", PATTERNS)
 def test_boundary_lengths(ctx, pattern):
+    """all three strand modes: `minus` and `both` with a pattern that is not its own mirror image ride on the same
+    register string (forward words of the reversed pattern, relabelled when the histogram is written out; round 3)"""
     rng = np.random.default_rng(len(pattern) * 977 + pattern.count("1"))
     records = [clean(rng, n, lower=(i % 3 == 0)) for i, n in enumerate(LENGTHS)]
     order = rng.permutation(len(records))          # starts at every alignment, a different record last in the buffer
-    check(ctx, [records[i] for i in order], pattern)
+    check(ctx, [records[i] for i in order], pattern, strands=("both", "plus", "minus"))
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -78,10 +81,15 @@ def test_long_record_and_windows(ctx):
     big = clean(rng, 300000)
     check(ctx, [clean(rng, 777), big, clean(rng, 5)], "1111")
     check(ctx, [big], "11011011", strands=("both",))
+    # chunks of one record sharing a histogram in the relabelled layouts; a separator sends one of its chunks down the general path
+    dirty = bytearray(big)
+    dirty[123456] = ord("N")
+    check(ctx, [clean(rng, 3000), bytes(dirty), clean(rng, 2017)], "1101", strands=("both", "minus"))
+    check(ctx, [bytes(dirty)[:9000], clean(rng, 4100)], "110100111", strands=("both", "minus"))
     seq = np.frombuffer(big, dtype=np.uint8)
     begins = np.arange(0, 300000 - 5000, 1777, dtype=np.uint64)
     ends = begins + np.uint64(5000)
-    for pattern, strand in (("1111", "both"), ("111", "plus")):
+    for pattern, strand in (("1111", "both"), ("111", "plus"), ("1101", "both"), ("10011", "minus")):
         counts, totals = ctx.count_profiles_ranges(seq, begins, ends, pattern, strand)
         oc, ot = oracle.compute_counts([big[int(b):int(e)] for b, e in zip(begins, ends)], pattern, strand)
         assert np.array_equal(counts.astype(np.int64), oc)

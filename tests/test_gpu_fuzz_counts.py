@@ -1,4 +1,4 @@
-"""Seeded fuzz of stage 1: random spaced-word patterns (window up to 32, up to 8 ones) on random records with
+"""Seeded fuzz of stage 1: random spaced-word patterns (window up to 64, up to 8 ones) on random records with
 separators, lower case and IUPAC symbols, all strands - bit-exact against the oracle (which the goldens pin to the
 reference's cut_sequence_and_count_pattern / select_strand)."""
 import numpy as np
@@ -20,9 +20,9 @@ def ctx():
     c.close()
 
 
-def random_pattern(rng):
+def random_pattern(rng, wide=False):
     k = int(rng.integers(1, 9))
-    w = int(rng.integers(k, 33))
+    w = int(rng.integers(33, 65)) if wide else int(rng.integers(k, 33))
     pos = np.sort(rng.choice(w, size=k, replace=False))
     if rng.random() < 0.7:                       # usually a '1' at both ends, as real spaced seeds have
         pos[0], pos[-1] = 0, w - 1
@@ -51,6 +51,22 @@ def test_random_patterns_and_records(ctx, seed):
     rng = np.random.default_rng(1000 + seed)
     pattern = random_pattern(rng)
     records = random_records(rng, 40)
+    seq = np.frombuffer(b"".join(records), dtype=np.uint8)
+    off = np.zeros(len(records) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in records])
+    for strand in ("both", "plus", "minus"):
+        counts, totals = ctx.count_profiles(seq, off, pattern, strand)
+        oc, ot = oracle.compute_counts(records, pattern, strand)
+        assert np.array_equal(counts.astype(np.int64), oc), (pattern, strand)
+        assert np.array_equal(totals.astype(np.int64), ot), (pattern, strand)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_wide_patterns_and_records(ctx, seed):
+    """windows of 33..64 positions: the 128-bit rolling registers, long records across chunks included"""
+    rng = np.random.default_rng(5000 + seed)
+    pattern = random_pattern(rng, wide=True)
+    records = random_records(rng, 30)
     seq = np.frombuffer(b"".join(records), dtype=np.uint8)
     off = np.zeros(len(records) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(r) for r in records])

@@ -50,6 +50,22 @@ def test_counts_bit_exact_vs_reference(ctx, prof, pattern, strand):
     assert np.array_equal(freq, prof["freq_%s_%s" % (pattern, strand)])      # bit-exact float64
 
 
+WIDE_PATTERNS = ["1" + "0" * 31 + "1", "1101" + "0" * 36 + "1", "11" + "0" * 30 + "101" + "0" * 27 + "11"]
+
+
+@pytest.mark.parametrize("pattern", WIDE_PATTERNS)
+@pytest.mark.parametrize("strand", STRANDS)
+def test_wide_window_counts_bit_exact_vs_reference(ctx, golden_dir, pattern, strand):
+    """spaced seeds of 33 / 41 / 64 positions (128-bit rolling window): the reference takes any pattern length
+    (bin/phyloligo.py:622-628); vectors produced by its cut_sequence_and_count_pattern"""
+    g = np.load(os.path.join(golden_dir, "profiles_wide.npz"))
+    contigs = [bytes(c) for c in g["contigs"]]
+    seq, offsets = pack(contigs)
+    counts, totals = ctx.count_profiles(seq, offsets, pattern, strand)
+    assert np.array_equal(counts.astype(np.int64), g["counts_%s_%s" % (pattern, strand)])
+    assert np.array_equal(totals.astype(np.int64), g["totals_%s_%s" % (pattern, strand)])
+
+
 @pytest.mark.parametrize("key", ["1111_both", "11_plus", "1101_minus", "11011011_both"])
 @pytest.mark.parametrize("metric", ["Eucl", "JSD", "BC"])
 def test_distances_vs_reference(ctx, dist, key, metric):

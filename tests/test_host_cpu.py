@@ -33,9 +33,14 @@ def test_pattern_info_and_errors():
     assert pa.pattern_info(4) == (4, 4, 256)
     assert pa.pattern_info("11011011") == (8, 6, 4096)
     assert pa.pattern_info("1" + "0" * 30 + "1") == (32, 2, 16)
-    for bad in ("", "000", "12", "1" * 9, "1" + "0" * 32 + "1"):
+    assert pa.pattern_info("1" + "0" * 31 + "1") == (33, 2, 16)            # wider than 32: two 64-bit window halves
+    assert pa.pattern_info("11" + "0" * 30 + "101" + "0" * 27 + "11") == (64, 6, 4096)
+    for bad in ("", "000", "12", "1" * 9, "1" + "0" * 63 + "1"):
         with pytest.raises(pa.PhyloligoError):
             pa.pattern_info(bad)
+    with pytest.raises(pa.PhyloligoError) as e:
+        pa.pattern_info("1" + "0" * 63 + "1")                                 # 65 positions: outside the envelope
+    assert e.value.status == _lib.PO_EUNSUPPORTED
 
 
 def test_no_cpu_fallback():

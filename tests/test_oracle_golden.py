@@ -149,3 +149,18 @@ def test_fasta_cases_downstream_of_the_parser(golden_dir):
             assert np.array_equal(totals, g["totals_%s_%s_%s" % (name, pat, strand)])
             if len(seqs):
                 assert np.array_equal(po.counts_to_frequencies(counts, totals), g["freq_%s_%s_%s" % (name, pat, strand)])
+
+
+WIDE_PATTERNS = ["1" + "0" * 31 + "1", "1101" + "0" * 36 + "1", "11" + "0" * 30 + "101" + "0" * 27 + "11"]
+
+
+@pytest.mark.parametrize("pattern", WIDE_PATTERNS)
+@pytest.mark.parametrize("strand", STRANDS)
+def test_wide_patterns_bit_exact(golden_dir, pattern, strand):
+    """spaced seeds of 33 / 41 / 64 positions: the reference's own counts (profiles_wide.npz)"""
+    g = np.load(os.path.join(golden_dir, "profiles_wide.npz"))
+    contigs = [bytes(c) for c in g["contigs"]]
+    counts, totals = po.compute_counts(contigs, pattern, strand)
+    assert np.array_equal(counts, g["counts_%s_%s" % (pattern, strand)])
+    assert np.array_equal(totals, g["totals_%s_%s" % (pattern, strand)])
+    assert totals.sum() > 0
