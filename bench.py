@@ -34,7 +34,7 @@ F64_MFMA_PEAK_TF = 78.6   # v_mfma_f64_16x16x4_f64 dense peak
 
 KERNEL_NAMES = {1: "valu_tile_kernel<JSD>", 2: "valu_tile_kernel<BC>", 3: "gram_tile_kernel (f64 MFMA)",
                 4: "gram_i8_tile_kernel (exact int8 MFMA)", 5: "kt_tile_kernel",
-                6: "jsd_lut_tile_kernel (equal-total record blocks) + valu_tile_kernel<JSD> (rest)",
+                6: "jsd_lut_rows_kernel (equal-total record blocks) + valu_tile_kernel<JSD> (rest)",
                 7: "bc_sad_tile_kernel (equal-total record blocks) + valu_tile_kernel<BC> (rest)",
                 8: "pairdot_tile_kernel<KT> (materialised pair-sign Gram on the matrix cores)",
                 9: "pairdot_tile_kernel<BC> (thermometer planes: sum of min on the matrix cores)"}
@@ -135,6 +135,93 @@ def hbm_roofline(algo_bytes, ms, **extra):
     return d
 
 
+def path_lines(ctx, seq, offsets, counts, totals, n, dim, metric, pattern, dev, stage1_ms, matrix_ms):
+    """Every step of the path either side of the timed matrix, each as its own line (reference: main(),
+    /root/reference/phylopackage/bin/phyloligo.py:1036-1068 - read the assembly, profile, distances, write).
+    h2d: sequence bytes + offsets host -> HBM; d2h: the float32 matrix (the --large memmap container type,
+    bin/phyloligo.py:413) HBM -> pageable host memory through po_pairwise's pinned ring; container: compute_distances(...,
+    large="memmap") = row blocks computed, copied and pwrite()n into the raw float32 file; e2e: the CLI itself in a child
+    process on a FASTA file of this assembly (process start and imports included)."""
+    import shutil
+    import subprocess
+    import tempfile
+    import torch
+    from phyloligo_amd import phyloligo as P
+    from phyloligo_amd import synthetic
+    lines = {"workload": "%d contigs, dim %d, -d %s" % (n, dim, metric), "stage1_ms": stage1_ms, "matrix_ms": matrix_ms,
+             "note": "none of these is part of `value` (matrix resident in HBM)"}
+    # ---- H2D of the assembly ----
+    off64 = offsets.astype(np.int64)
+    torch.cuda.synchronize(dev)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        d_seq = torch.from_numpy(seq).to(dev)
+        d_off = torch.from_numpy(off64).to(dev)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) * 1e3
+        best = dt if best is None else min(best, dt)
+    del d_seq, d_off
+    lines["h2d_ms"] = best
+    lines["h2d_bytes"] = int(seq.nbytes + off64.nbytes)
+    # ---- D2H of the float32 matrix through the host-pointer entry point (H2D of the counts + matrix + D2H ring) ----
+    c_h, t_h = counts.cpu().numpy().astype(np.uint32), totals.cpu().numpy().astype(np.uint64)
+    need = n * n * 4
+    import psutil
+    if psutil.virtual_memory().available > 3 * need:
+        host = np.empty((n, n), dtype=np.float32)
+        t0 = time.perf_counter()
+        _, st = ctx.pairwise(c_h, t_h, metric, dtype="float32", out=host, want_stats=True)
+        wall = (time.perf_counter() - t0) * 1e3
+        lines["d2h_ms"] = wall - st["total_ms"]
+        lines["d2h_bytes"] = int(need)
+        lines["d2h_gb_per_s"] = need / max(1e-9, (wall - st["total_ms"]) * 1e-3) / 1e9
+        lines["host_pointer_call_ms"] = wall
+        lines["pairs_per_s_pcie_inclusive"] = n * (n - 1) / 2.0 / (wall * 1e-3)
+        del host
+    else:
+        lines["d2h_ms"] = None
+        lines["d2h_note"] = "skipped: not enough host memory for a %d-byte result" % need
+    ctx.trim()                                                    # the 10 GB staging of the host-pointer form goes back
+    # ---- the raw float32 container and the CLI end to end, on a FASTA file of this assembly ----
+    tmp_root = os.environ.get("TMPDIR") or tempfile.gettempdir()
+    if shutil.disk_usage(tmp_root).free < need + seq.nbytes * 2 + (1 << 30):
+        lines["container_write_ms"] = None
+        lines["container_note"] = "skipped: not enough free space under %s" % tmp_root
+        return lines
+    with tempfile.TemporaryDirectory(dir=tmp_root) as tmp:
+        fa = os.path.join(tmp, "assembly.fa")
+        with open(fa, "wb") as fh:
+            fh.write(synthetic.fasta_bytes(seq, offsets))
+        lines["fasta_bytes"] = os.path.getsize(fa)
+        t0 = time.perf_counter()
+        freq, _ = P.compute_frequencies("hip", "memmap", fa, pattern, "both", 250, 4, tmp)
+        lines["ingest_and_profiles_ms"] = (time.perf_counter() - t0) * 1e3
+        out = os.path.join(tmp, "matrix.f32")
+        t0 = time.perf_counter()
+        P.compute_distances("hip", "memmap", freq, None, out, metric, 4, 250, tmp)
+        lines["container_path_ms"] = (time.perf_counter() - t0) * 1e3           # compute + D2H + pwrite, overlapped
+        lines["container_bytes"] = os.path.getsize(out)
+        lines["container_write_ms"] = lines["container_path_ms"] - matrix_ms
+        lines["container_gb_per_s"] = lines["container_bytes"] / (lines["container_path_ms"] * 1e-3) / 1e9
+        os.remove(out)
+        del freq
+        ctx.trim()
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        cmd = [sys.executable, "-m", "phyloligo_amd", "-i", fa, "-p", pattern, "-d", metric, "--method", "joblib", "--large", "memmap",
+               "-o", out, "-w", tmp]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        lines["e2e_cli_wall_s"] = time.perf_counter() - t0
+        lines["e2e_cli"] = "python -m phyloligo_amd -i assembly.fa -p %s -d %s --method joblib --large memmap -o matrix.f32" % (pattern, metric)
+        lines["e2e_cli_rc"] = r.returncode
+        if r.returncode == 0:
+            lines["e2e_cli_container_bytes"] = os.path.getsize(out)
+        else:
+            lines["e2e_cli_stderr"] = r.stderr[-400:]
+    return lines
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +235,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 / KT extras in config.other_configs")
     ap.add_argument("--no-complete-rows", action="store_true", help="N>1: skip timing the optional row-completing exchange")
+    ap.add_argument("--no-path-lines", action="store_true", help="skip config.path_lines (H2D, D2H, container write, end-to-end CLI wall)")
     args = ap.parse_args()
 
     import torch
@@ -280,12 +368,15 @@ def main():
         # compulsory HBM bytes per unordered pair = two mirrored float64 outputs + the
         # amortised one-time read of both profiles (uint32 counts)
         bytes_per_pair = 2 * 8 + 2 * dim * 4 / (n - 1)
-        traffic = None
-        busy = {}
+        traffic_all, busy = {}, {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh).get("%s_n%d_d%d" % (args.metric, n, dim))
+                traffic_all = json.load(fh)
+        # HBM-side bytes per launch of that kernel from the committed counter passes (FETCH_SIZE x 2 + WRITE_SIZE, separate
+        # rocprofv3 --pmc passes, gfx950 correction: MI355X_MICROARCH.md); the key names the workload it was measured on
+        traffic = traffic_all.get("%s_n%d_d%d" % (args.metric, n, dim))
+        traffic_source = traffic_all.get("_detail", {}).get("source")
         bpath = os.path.join(ROOT, "profiles", "pmc_busy.json")
         if os.path.exists(bpath):
             with open(bpath) as fh:
@@ -299,9 +390,9 @@ def main():
             res = max((k for k in ("valu", "lds", "mfma") if b.get(k) is not None), key=lambda k: b[k])
             return {"resource": res, "busy": b[res], "all": {k: b.get(k) for k in ("valu", "lds", "mfma")}, "source": busy.get("_source")}
 
-        main_key = {6: "jsd_lut_tile_kernel", 1: "valu_tile_kernel<JSD>", 4: "gram_i8_tile_kernel<1>", 3: "gram_tile_kernel<f64>",
+        main_key = {6: "jsd_lut_rows_kernel", 1: "valu_tile_kernel<JSD>", 4: "gram_i8_tile_kernel<1>", 3: "gram_tile_kernel<f64>",
                     7: "bc_sad_tile_kernel", 2: "valu_tile_kernel<BC>", 8: "pairdot_tile_kernel<KT>", 9: "pairdot_tile_kernel<BC>"}.get(main_kernel_id)
-        roof = hbm_roofline(bytes_per_pair * rank_pairs, kernel_ms, traffic=traffic if world == 1 else None,
+        roof = hbm_roofline(bytes_per_pair * rank_pairs, kernel_ms, traffic=traffic if world == 1 else None, traffic_source=traffic_source,
                             kernel=KERNEL_NAMES.get(main_kernel_id, "tile kernel"), kernel_ms=kernel_ms, bytes_per_pair=bytes_per_pair,
                             binding=binding(main_key),
                             note="nominal roof per north_star; the JSD tile kernels are bound by LDS / vector-ALU issue, "
@@ -312,7 +403,8 @@ def main():
             g_ms = float(np.mean([x["total_ms"] for x in gms]))
             g_kms = float(np.mean([x["kernel_ms"] for x in gms]))
             general = {"ms": g_ms, "kernel_ms": g_kms, "pairs_per_s": rank_pairs / (g_ms * 1e-3),
-                       "roofline": hbm_roofline(bytes_per_pair * rank_pairs, g_kms, binding=binding("valu_tile_kernel<JSD>")),
+                       "roofline": hbm_roofline(bytes_per_pair * rank_pairs, g_kms, binding=binding("valu_tile_kernel<JSD>"),
+                                                traffic=traffic_all.get("JSD_general_n%d_d%d" % (n, dim))),
                        "what": "valu_tile_kernel<JSD>: the kernel a ragged real assembly gets (totals differ inside every "
                                "128-record block, or counts above 127)"}
         workload = ("%s: %d synthetic contigs x %d bp (seed %d), pattern %s both strands, -d %s, float64 matrix resident in HBM"
@@ -361,6 +453,7 @@ def main():
                             "kernel_id": best["kernel_id"], "kernel": KERNEL_NAMES.get(best["kernel_id"]), "rc_folded": best["rc_folded"],
                             "roofline": hbm_roofline(bpp * pairs, best["kernel_ms"])}
                 e = timed(counts, totals, "Eucl")
+                e["roofline"]["traffic"] = traffic_all.get("Eucl_n%d_d%d" % (n, dim))
                 e["roofline"]["bound"] = "hbm-store"
                 e["roofline"]["binding"] = binding("gram_i8_tile_kernel<1>")
                 e["roofline"]["note"] = ("exact int8-MFMA Gram: matrix-core time ~0.1 ms, the kernel is bound by writing 16 B per pair; "
@@ -370,21 +463,31 @@ def main():
                 tf = 2.0 * dim * pairs / (f["kernel_ms"] * 1e-3) / 1e12
                 f["roofline"] = {"bound": "mfma-f64", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TF,
                                  "flops_per_pair": 2 * dim, "binding": binding("gram_tile_kernel<f64>"),
+                                 "traffic": traffic_all.get("Eucl_f64_n%d_d%d" % (n, dim)),
                                  "note": "forced float64 path (v_mfma_f64_16x16x4_f64), the path north_star's MFMA target is quoted on"}
                 others["C3 Eucl k=4 (float64 MFMA path, table_path=False)"] = f
                 k = timed(counts, totals, "KT")
                 k["roofline"]["binding"] = binding("pairdot_tile_kernel<KT>")
+                k["roofline"]["traffic"] = traffic_all.get("KT_n%d_d%d" % (n, dim))
                 others["C2-size KT k=4"] = k
                 seq5, off5 = synthetic.contig_bytes(n, args.length, seed=synthetic.SEEDS["C5"])
                 c5, t5 = ctx.count_profiles(torch.from_numpy(seq5).to(dev), torch.from_numpy(off5.astype(np.int64)).to(dev),
                                             "11011011", "both")
                 b5 = timed(c5, t5, "BC")
                 b5["roofline"]["binding"] = binding("pairdot_tile_kernel<BC>" if b5["kernel_id"] == 9 else "bc_sad_tile_kernel")
+                b5["roofline"]["traffic"] = traffic_all.get("BC_n%d_d%d" % (n, c5.shape[1]) if b5["kernel_id"] == 9 else "BC_sad_n%d" % n)
                 others["C5 BC pattern 11011011"] = b5
                 del c5, t5
             except Exception as exc:             # never let the extras break the headline line
                 others["error"] = repr(exc)
             result["config"]["other_configs"] = others
+        if world == 1 and args.metric == "JSD" and not args.no_path_lines:
+            # "stage-1 time, H2D, D2H and .mat writing are reported as separate lines, never hidden" - none of them
+            # is part of `value`.  Measured on THIS workload (the C2 assembly when the defaults are used).
+            try:
+                result["config"]["path_lines"] = path_lines(ctx, seq, offsets, counts, totals, n, dim, args.metric, args.pattern, dev, stage1_ms, ms_per_step)
+            except Exception as exc:             # never let the extras break the headline line
+                result["config"]["path_lines"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import phyloligo_oracle as po
             freq = po.counts_to_frequencies(counts.cpu().numpy().astype(np.int64), totals.cpu().numpy())

@@ -7,8 +7,8 @@
 //     S = sum_w (a_w+b_w) ln(a_w+b_w) = (1/n) sum_w T[ca_w + cb_w] - 2 ln n,   T[x] = x ln x,
 // and the per-word, per-pair work collapses from a float64 logarithm to ONE integer add, ONE LDS read
 // and ONE float64 add.  T[x] for x = 0..255 sits in LDS replicated 32x (entry x, copy c at byte
-// x*256 + c*8) so that the per-lane lookups of a wave never conflict; counts are staged pre-shifted by 8
-// bits, so a lookup address is a single v_add3_u32.
+// x*256 + c*8) so that the per-lane lookups of a wave never conflict; counts are kept pre-shifted by 8
+// bits (and the column side with its lane's copy offset baked in), so a lookup address is a single v_add_u32.
 //
 // Eligibility is decided per tile on the device: classify_kernel marks each block of 128 records with its
 // common total (0 = mixed / empty / a count above 127); a tile (I,J) takes this path iff both classes are
@@ -20,15 +20,15 @@
 namespace {
 
 constexpr int TM = 128, TN = 128;
-constexpr int KC = 8;
 constexpr int kLutEntries = 256;                       // sums 0..255  -> counts up to 127 (fixed-length contigs up to ~10 kb at k=4)
 constexpr int kLutBytes = kLutEntries * 256;           // 32 copies x 8 B per entry
-constexpr int kStageWords = KC * (TM + TN);            // uint32 per buffer
 constexpr double LN2 = 0.693147180559945309417232121458;
 
 // Ct[d][npad] = counts[n][d] << 8 (uint32, transposed, zero padded to D8 x npad)
+// ctb (may be NULL): the same with the byte offset of the table copy of the lane that will look the column up baked in:
+// column record j is looked up by lane (j >> 1) & 63 of a wave, which uses copy (j >> 1) & 31 (8 bytes each)
 __global__ __launch_bounds__(256) void prep_counts_kernel(const uint32_t* __restrict__ counts, uint64_t n, uint32_t dim,
-                                                          uint64_t npad, uint32_t* __restrict__ ct,
+                                                          uint64_t npad, uint32_t* __restrict__ ct, uint32_t* __restrict__ ctb,
                                                           uint32_t* __restrict__ maxcount) {
     __shared__ uint32_t tile[64][65];
     __shared__ uint32_t blkmax;
@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void prep_counts_kernel(const uint32_t* __rest
     __syncthreads();
     if (threadIdx.x == 0 && blkmax > *maxcount) atomicMax(maxcount, blkmax);   // racy pre-check skips redundant atomics
     for (uint32_t r = ty; r < 64; r += 4)
-        if (d0 + r < ((dim + 7u) & ~7u) && n0 + tx < npad) ct[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r];
+        if (d0 + r < ((dim + 7u) & ~7u) && n0 + tx < npad) {
+            ct[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r];
+            if (ctb) ctb[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r] + ((((uint32_t)(n0 + tx) >> 1) & 31u) << 3);
+        }
 }
 
 // cls[b] = common word total of records [128b, 128b+128) (padding ignored), 0 if they differ, if one is
@@ -76,126 +79,158 @@ __global__ void lut_table_kernel(double* __restrict__ lut) {
 
 
 
-// RPT rows per lane: 8 -> 256 lanes per 128 x 128 tile, 4 -> 512 lanes (more waves per SIMD to hide the
-// LDS round trips; the table is shared by twice as many waves).
-template <typename OUT, int RPT>
-__global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void jsd_lut_tile_kernel(po_tile_args A, const uint32_t* __restrict__ ct,
-                                                                                  const double* __restrict__ lut,
-                                                                                  const unsigned long long* __restrict__ cls) {
-    constexpr int NT = 2048 / RPT;                                               // lanes per workgroup
+// ---- the tile kernel: wave-uniform rows (round 3) ------------------------------------------------------------------
+// A wave owns RW rows x 128 columns of the tile, a lane two adjacent columns of it.  The RW row counts of a word are the
+// same for every lane: they are fetched by ONE scalar load (s_load_dwordx8 / x16 from the transposed count matrix) and sit in
+// scalar registers, so that a lookup address is one v_add_u32 in its short encoding (scalar row term + vector column term) and
+// nothing else; the two column counts of a word come straight from global memory (8 bytes per lane, 512 contiguous bytes per
+// wave, requested kPF words ahead) with the lane's table copy baked in (ctb).  No operand goes through LDS any more - no
+// LDS-DMA staging, no barrier in the loop - and the LDS data path serves nothing but the lookups (the round-1/2 kernel, a
+// 4 x 8 register block per lane with both operands staged through LDS, spent 1 ds_read_b128 + 4 ds_read_b64 of every 84 LDS
+// cycles and 10 of every 42 vector adds on operands; it measured 15.1 - 15.4 ms at C2 against 15.0 - 15.2 ms for this one on
+// the same box, profiles/r03_jsd_lut.txt).  The scalar loads share lgkmcnt with the lookups and come back out of order: the next
+// word's row counts are requested before the current word's lookups and waited for behind them with lgkmcnt(0) (the
+// compiler does not know about them; its own counted waits only ever wait longer because of them).
+typedef uint32_t po_u32x16 __attribute__((ext_vector_type(16)));
+constexpr int kRowsMirrorCols = 64;                     // columns per transposition round of the mirrored tile
+constexpr int kRowsMirrorBytes = kRowsMirrorCols * kMirrorLdsStride * 8;
+constexpr int kRowsLdsBytes = kRowsMirrorBytes > kLutBytes ? kRowsMirrorBytes : kLutBytes;
+
+template <int RW> struct rows_vec;
+template <> struct rows_vec<16> {
+    typedef po_u32x16 type;
+    static __device__ __forceinline__ type load(const uint32_t* p) { type v; asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p)); return v; }
+};
+
+// RW = 16 rows per wave: 8 waves per tile (512 lanes), 4 waves per SIMD at two workgroups per CU.  (8 rows per wave, 16 waves per
+// tile and 8 per SIMD measured 15.3 - 15.7 ms: more waves do not buy more overlap.)
+template <typename OUT, int RW>
+__global__ __launch_bounds__(64 * TM / RW, 4) void jsd_lut_rows_kernel(po_tile_args A, const uint32_t* __restrict__ ct,
+                                                              const uint32_t* __restrict__ ctb, const double* __restrict__ lut,
+                                                              const unsigned long long* __restrict__ cls) {
+    typedef typename rows_vec<RW>::type AV;
+    constexpr uint32_t NT = 64 * TM / RW, NW = TM / RW;
+    constexpr int kPF = 4;                                                       // words of column counts in flight per lane
     extern __shared__ __align__(16) unsigned char smem[];
-    double* tab = reinterpret_cast<double*>(smem);                               // [128][32]
-    uint32_t* stage = reinterpret_cast<uint32_t*>(smem + kLutBytes);             // [2][A: KC x 128 | B: KC x 128]
-
-    const uint32_t t = threadIdx.x;
-    const uint32_t tx = t & 15, ty = t >> 4;
-    const uint32_t lane = t & 63, wave = t >> 6;
-
+    double* tab = reinterpret_cast<double*>(smem);                               // [256][32]; the mirror scratch afterwards
+    const uint32_t t = threadIdx.x, lane = t & 63;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
     uint32_t ti, tj;
     po_tile_coords(A, TM, blockIdx.x, ti, tj);
     const unsigned long long ntot = cls[ti];
     if (ntot == 0 || cls[tj] != ntot) return;                                    // valu_tile_kernel<JSD> owns this tile
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
-
     {
-        const uint4* src = reinterpret_cast<const uint4*>(lut);                  // already replicated: 16-byte copies
+        const uint4* src = reinterpret_cast<const uint4*>(lut);
         uint4* dst = reinterpret_cast<uint4*>(tab);
         for (uint32_t v = t; v < kLutBytes / 16; v += NT) dst[v] = src[v];
     }
-
-    double acc[RPT][8];
+    double acc[RW][2];
 #pragma unroll
-    for (int a = 0; a < RPT; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
+    for (int r = 0; r < RW; ++r) acc[r][0] = acc[r][1] = 0.0;
 
-    // staging: one LDS-DMA instruction moves 64 lanes x 16 B = two 512-byte word rows.  With 4 waves
-    // each wave takes words 2w, 2w+1 of the A block and of the B block; with 8 waves, waves 0-3 take
-    // the A block and waves 4-7 the B block.
-    auto gstage = [&](uint32_t k0, uint32_t buf) {
-        const uint32_t w4 = wave & 3;
-        const uint32_t k = w4 * 2 + (lane >> 5);
-        const uint32_t* row = ct + (uint64_t)(k0 + k) * A.npad + (lane & 31) * 4;
-        uint32_t* dst = stage + buf * kStageWords + w4 * 2 * TM;
-        if (RPT == 8) {
-            po_glds16(row + i0, dst);
-            po_glds16(row + j0, dst + KC * TM);
-        } else if (wave < 4) {
-            po_glds16(row + i0, dst);
-        } else {
-            po_glds16(row + j0, dst + KC * TM);
+    const uint32_t* pa = ct + i0 + RW * wv;                                      // + k * npad: wave uniform
+    const uint32_t* pb = ctb + j0;                                               // + k * npad, + 2 lane
+    const uint32_t lb = 2 * lane;
+    const uint32_t tbase = po_lds_addr(tab);
+    const uint32_t kmax = A.dim - 1;                                             // dim is a multiple of 8 (zero padded words)
+    uint2 bq[kPF];
+#pragma unroll
+    for (int q = 0; q < kPF; ++q) bq[q] = *reinterpret_cast<const uint2*>(pb + (uint64_t)min((uint32_t)q, kmax) * A.npad + lb);
+    AV a_cur = rows_vec<RW>::load(pa);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a_cur) :: "memory");
+    __syncthreads();                                                             // the table is in LDS
+    for (uint32_t k0 = 0; k0 < A.dim; k0 += kPF) {
+#pragma unroll
+        for (int q = 0; q < kPF; ++q) {
+            const uint32_t k = k0 + q;
+            if (k == A.dbl_at) {                                                 // folded operands (po_fold.hip)
+#pragma unroll
+                for (int r = 0; r < RW; ++r) { acc[r][0] *= 2.0; acc[r][1] *= 2.0; }
+            }
+            AV a_next = rows_vec<RW>::load(pa + (uint64_t)min(k + 1, kmax) * A.npad);
+            const uint32_t b0 = bq[q].x, b1 = bq[q].y;
+            bq[q] = *reinterpret_cast<const uint2*>(pb + (uint64_t)min(k + kPF, kmax) * A.npad + lb);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const uint32_t ar = a_cur[r] + tbase;                            // scalar add
+                acc[r][0] += po_lds_read_f64(ar + b0);
+                acc[r][1] += po_lds_read_f64(ar + b1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a_next) :: "memory");
+            a_cur = a_next;
         }
-    };
-    gstage(0, 0);
-    __syncthreads();
-
-    const uint32_t tcopy = po_lds_addr(tab) + (lane & 31) * 8;
-    auto double_sums = [&]() {                                                   // folded operands (po_fold.hip)
-#pragma unroll
-        for (int a = 0; a < RPT; ++a)
-#pragma unroll
-            for (int b = 0; b < 8; ++b) acc[a][b] *= 2.0;
-    };
-    uint32_t cur = 0;
-    for (uint32_t k0 = 0; k0 < A.dim; k0 += KC) {
-        if (k0 + KC < A.dim) gstage(k0 + KC, cur ^ 1);
-        if (k0 == A.dbl_at) double_sums();
-        const uint32_t* sA = stage + cur * kStageWords + ty * RPT;
-        const uint32_t* sB = stage + cur * kStageWords + KC * TM + tx * 2;
-#pragma unroll 2
-        for (int k = 0; k < KC; ++k) {
-            uint32_t a[RPT];                               // table base (this lane's copy) folded into the row side: RPT adds, not 8
-#pragma unroll
-            for (int q = 0; q < RPT / 4; ++q) {
-                const uint4 av = *reinterpret_cast<const uint4*>(sA + k * TM + 4 * q);
-                a[4 * q] = av.x + tcopy; a[4 * q + 1] = av.y + tcopy; a[4 * q + 2] = av.z + tcopy; a[4 * q + 3] = av.w + tcopy;
-            }
-            uint32_t b[8];                                 // columns 32*q + 2*tx + {0,1}
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint2 bv = *reinterpret_cast<const uint2*>(sB + k * TN + 32 * q);
-                b[2 * q] = bv.x; b[2 * q + 1] = bv.y;
-            }
-            // the 8 lookups of register-block row ia+1 are in flight while row ia is accumulated
-            double tv[2][8];
-#pragma unroll
-            for (int ib = 0; ib < 8; ++ib) tv[0][ib] = po_lds_read_f64(a[0] + b[ib]);
-#pragma unroll
-            for (int ia = 0; ia < RPT; ++ia) {
-                if (ia + 1 < RPT) {
-#pragma unroll
-                    for (int ib = 0; ib < 8; ++ib) tv[(ia + 1) & 1][ib] = po_lds_read_f64(a[ia + 1] + b[ib]);
-                }
-#pragma unroll
-                for (int ib = 0; ib < 8; ++ib) acc[ia][ib] += tv[ia & 1][ib];
-            }
-        }
-        __syncthreads();
-        cur ^= 1;
     }
-    if (A.dbl_at != PO_NO_DOUBLING && A.dbl_at >= A.dim) double_sums();
+    if (A.dbl_at != PO_NO_DOUBLING && A.dbl_at >= A.dim) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) { acc[r][0] *= 2.0; acc[r][1] *= 2.0; }
+    }
 
-    // ---- epilogue: JSD = 1/2 (E_i + E_j - S) + ln 2,  S = Tsum/n - 2 ln n ----------------------------
+    // ---- epilogue: JSD = 1/2 (E_i + E_j - S) + ln 2,  S = Tsum/n - 2 ln n  (same operations, same order as the kernel above) ----
     const double inv_n = 1.0 / (double)ntot;
     const double two_ln_n = 2.0 * log((double)ntot);
     const double* st0 = A.rowstat;
-    double ei[RPT];
+    const uint64_t jc = j0 + 2 * lane;
+    const double ej0 = st0[min(jc, A.npad - 1)], ej1 = st0[min(jc + 1, A.npad - 1)];
 #pragma unroll
-    for (int ia = 0; ia < RPT; ++ia) ei[ia] = st0[i0 + ty * RPT + ia];
+    for (int r = 0; r < RW; ++r) {
+        const uint64_t i = i0 + RW * wv + r;
+        const double ei = st0[i];
+        double v0 = fmax(0.5 * (ei + ej0 - fma(acc[r][0], inv_n, -two_ln_n)) + LN2, 0.0);
+        double v1 = fmax(0.5 * (ei + ej1 - fma(acc[r][1], inv_n, -two_ln_n)) + LN2, 0.0);
+        if (i == jc) v0 = 0.0;
+        if (i == jc + 1) v1 = 0.0;
+        acc[r][0] = v0; acc[r][1] = v1;
+    }
+    // the tile itself: a row of it is 1 KiB of one wave-instruction
+    OUT* out = static_cast<OUT*>(A.out);
+    const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
+    const bool vec_out = (A.ld_out & 1) == 0 && ((j0 - A.col_begin) & 1) == 0 &&
+                         (reinterpret_cast<uintptr_t>(A.out) & (2 * sizeof(OUT) - 1)) == 0 && j0 >= A.col_begin;
 #pragma unroll
-    for (int ib = 0; ib < 8; ++ib) {
-        const uint64_t j = min(j0 + 32 * (ib >> 1) + 2 * tx + (ib & 1), A.npad - 1);
-        const double ej = st0[j];
-#pragma unroll
-        for (int ia = 0; ia < RPT; ++ia) {
-            const uint64_t i = i0 + ty * RPT + ia;
-            const double S = fma(acc[ia][ib], inv_n, -two_ln_n);
-            double v = fmax(0.5 * (ei[ia] + ej - S) + LN2, 0.0);
-            if (i == j) v = 0.0;
-            acc[ia][ib] = v;
+    for (int r = 0; r < RW; ++r) {
+        const uint64_t i = i0 + RW * wv + r;
+        if (i < A.row_begin || i >= n_rows) continue;
+        OUT* row = out + (i - A.row_begin) * A.ld_out;
+        if (vec_out && jc + 1 < n_cols) {
+            po_store2(row + (jc - A.col_begin), acc[r][0], acc[r][1]);
+        } else {
+            if (jc >= A.col_begin && jc < n_cols) po_out_store(&row[jc - A.col_begin], (OUT)acc[r][0]);
+            if (jc + 1 >= A.col_begin && jc + 1 < n_cols) po_out_store(&row[jc + 1 - A.col_begin], (OUT)acc[r][1]);
         }
     }
-    po_store_block<OUT, RPT, NT>(A, ti, tj, i0, j0, tx, ty, acc, reinterpret_cast<double*>(smem));
+    if (!po_tile_mirrors(A, ti, tj)) return;                                     // uniform over the workgroup
+    // the transposed tile, 64 columns at a time through LDS (the table is dead): full 1 KiB row pieces again
+    OUT* mir = static_cast<OUT*>(A.mirror);
+    double* lds = reinterpret_cast<double*>(smem);
+    const bool vec_mir = (A.ld_mirror & 1) == 0 && ((i0 - A.row_begin) & 1) == 0 &&
+                         (reinterpret_cast<uintptr_t>(A.mirror) & (2 * sizeof(OUT) - 1)) == 0 && i0 >= A.row_begin;
+#pragma unroll
+    for (int q = 0; q < TN / kRowsMirrorCols; ++q) {
+        __syncthreads();                                   // the table (q = 0) / the previous round has been read by everybody
+        if ((lane >> 5) == (uint32_t)q) {                  // the lanes holding columns [64 q, 64 q + 64)
+            const uint32_t c = 2 * (lane & 31);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                lds[c * kMirrorLdsStride + RW * wv + r] = acc[r][0];
+                lds[(c + 1) * kMirrorLdsStride + RW * wv + r] = acc[r][1];
+            }
+        }
+        __syncthreads();
+        for (uint32_t jq = wv; jq < kRowsMirrorCols; jq += NW) {                 // one wave per transposed row
+            const uint64_t j = j0 + kRowsMirrorCols * q + jq;
+            if (j < A.col_begin || j >= n_cols) continue;
+            const double2 w = *reinterpret_cast<const double2*>(lds + jq * kMirrorLdsStride + 2 * lane);
+            const uint64_t i = i0 + 2 * lane;
+            OUT* row = mir + (j - A.col_begin) * A.ld_mirror;
+            if (vec_mir && i + 1 < n_rows) {
+                po_store2(row + (i - A.row_begin), w.x, w.y);
+            } else {
+                if (i >= A.row_begin && i < n_rows) po_out_store(&row[i - A.row_begin], (OUT)w.x);
+                if (i + 1 >= A.row_begin && i + 1 < n_rows) po_out_store(&row[i + 1 - A.row_begin], (OUT)w.y);
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -204,7 +239,8 @@ size_t po_jsd_lut_workspace(uint64_t n, uint32_t dim) {
     const uint64_t npad = po_round_up(n ? n : 1, 128);
     return po_round_up(dim, 8) * npad * sizeof(uint32_t)      // Ct
            + po_round_up(npad / 128 * sizeof(unsigned long long), 16)   // cls
-           + kLutBytes + 256;                                   // replicated T + maxcount
+           + kLutBytes + 256                                    // replicated T + maxcount
+           + po_round_up(dim, 8) * npad * sizeof(uint32_t);     // Ct with the lanes' table copies baked in (rows kernel)
 }
 
 // Builds Ct, the table and the tile classes in ws (layout as sized above); returns the class array.
@@ -217,9 +253,10 @@ int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t
     base += po_round_up(npad / 128 * sizeof(unsigned long long), 16);
     double* lut = reinterpret_cast<double*>(base);
     uint32_t* maxcount = reinterpret_cast<uint32_t*>(base + kLutBytes);
+    uint32_t* ctb = reinterpret_cast<uint32_t*>(base + kLutBytes + 256);
     PO_HIP(hipMemsetAsync(maxcount, 0, sizeof(uint32_t), ctx->stream));
     dim3 grid((uint32_t)(npad / 64), (dim + 63) / 64);
-    hipLaunchKernelGGL(prep_counts_kernel, grid, dim3(256), 0, ctx->stream, d_counts, n, dim, npad, ct, maxcount);
+    hipLaunchKernelGGL(prep_counts_kernel, grid, dim3(256), 0, ctx->stream, d_counts, n, dim, npad, ct, ctb, maxcount);
     PO_CHECK_LAUNCH("prep_counts_kernel");
     hipLaunchKernelGGL(lut_table_kernel, dim3(kLutEntries), dim3(32), 0, ctx->stream, lut);
     PO_CHECK_LAUNCH("lut_table_kernel");
@@ -237,20 +274,21 @@ int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, cons
     const unsigned long long* cls = reinterpret_cast<const unsigned long long*>(base);
     base += po_round_up(a.npad / 128 * sizeof(unsigned long long), 16);
     const double* lut = reinterpret_cast<const double*>(base);
+    const uint32_t* ctb = reinterpret_cast<const uint32_t*>(base + kLutBytes + 256);
     (void)n;
     const uint64_t nblocks = po_tile_count(a, TM);
     if (tiles) *tiles += nblocks;
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
-    const size_t shmem = kLutBytes + 2 * kStageWords * sizeof(uint32_t);
-    // 4 rows per lane (512 lanes per tile); the 8-row / 256-lane variant measured slower (round 1)
+    constexpr int RWL = 16;
+    const size_t shmem = kRowsLdsBytes;
     if (a.out_f32) {
-        PO_SHMEM(ctx, (jsd_lut_tile_kernel<float, 4>), shmem);
-        hipLaunchKernelGGL((jsd_lut_tile_kernel<float, 4>), dim3((uint32_t)nblocks), dim3(512), shmem, ctx->stream, a, ct, lut, cls);
+        PO_SHMEM(ctx, (jsd_lut_rows_kernel<float, RWL>), shmem);
+        hipLaunchKernelGGL((jsd_lut_rows_kernel<float, RWL>), dim3((uint32_t)nblocks), dim3(64 * TM / RWL), shmem, ctx->stream, a, ct, ctb, lut, cls);
     } else {
-        PO_SHMEM(ctx, (jsd_lut_tile_kernel<double, 4>), shmem);
-        hipLaunchKernelGGL((jsd_lut_tile_kernel<double, 4>), dim3((uint32_t)nblocks), dim3(512), shmem, ctx->stream, a, ct, lut, cls);
+        PO_SHMEM(ctx, (jsd_lut_rows_kernel<double, RWL>), shmem);
+        hipLaunchKernelGGL((jsd_lut_rows_kernel<double, RWL>), dim3((uint32_t)nblocks), dim3(64 * TM / RWL), shmem, ctx->stream, a, ct, ctb, lut, cls);
     }
-    PO_CHECK_LAUNCH("jsd_lut_tile_kernel");
+    PO_CHECK_LAUNCH("jsd_lut_rows_kernel");
     return PO_OK;
 }

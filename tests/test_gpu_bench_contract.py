@@ -35,6 +35,13 @@ def test_bench_json_contract():
     gen = r["config"]["jsd_general_kernel_only"]
     assert gen["roofline"]["frac"] > 0 and gen["pairs_per_s"] < r["value"] * 1.5
     assert r["scaling"] == "weak" and "seed 50001" in r["config"]["workload"]
+    # stage 1, H2D, D2H and the container write as separate lines, never inside `value`
+    pl = r["config"]["path_lines"]
+    assert "error" not in pl, pl
+    for key in ("h2d_ms", "stage1_ms", "matrix_ms", "d2h_ms", "container_write_ms", "container_path_ms", "e2e_cli_wall_s"):
+        assert pl[key] is not None and pl[key] >= 0 or key == "container_write_ms", (key, pl)
+    assert pl["e2e_cli_rc"] == 0 and pl["e2e_cli_container_bytes"] == 3000 * 3000 * 4 == pl["container_bytes"] == pl["d2h_bytes"]
+    assert abs(pl["matrix_ms"] - r["ms_per_step"]) < 1e-9
 
 
 def test_bench_multi_rank_path_rehearsal():

@@ -20,7 +20,7 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], "**", "*.db"), recursive=Tru
     # the largest dispatch of each kernel (the N = 50 000 tile launch that did the work)
     for name, counter, val in c.execute("select kernel_name, counter_name, max(value) from counters_collection group by kernel_name, counter_name"):
         vals[short(name)][counter] = val
-KEYS = {"jsd_lut_tile_kernel<double, 4>": "jsd_lut_tile_kernel", "valu_tile_kernel<1, double, 4>": "valu_tile_kernel<JSD>",
+KEYS = {"jsd_lut_rows_kernel<double, 16>": "jsd_lut_rows_kernel", "valu_tile_kernel<1, double, 4>": "valu_tile_kernel<JSD>",
         "valu_tile_kernel<3, double, 8>": "valu_tile_kernel<BC>", "gram_i8_tile_kernel<1, 0, double>": "gram_i8_tile_kernel<1>",
         "gram_tile_kernel<0, double>": "gram_tile_kernel<f64>", "bc_sad_tile_kernel<double>": "bc_sad_tile_kernel",
         "pairdot_tile_kernel<1, 0, double>": "pairdot_tile_kernel<KT>", "pairdot_tile_kernel<1, 1, double>": "pairdot_tile_kernel<BC>",
