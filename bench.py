@@ -169,16 +169,22 @@ def path_lines(ctx, seq, offsets, counts, totals, n, dim, metric, pattern, dev, 
     need = n * n * 4
     import psutil
     if psutil.virtual_memory().available > 3 * need:
-        host = np.empty((n, n), dtype=np.float32)
-        t0 = time.perf_counter()
-        _, st = ctx.pairwise(c_h, t_h, metric, dtype="float32", out=host, want_stats=True)
-        wall = (time.perf_counter() - t0) * 1e3
+        first = None
+        for _ in range(2):                                        # the first call also grows the 10 GB device staging buffer
+            host = np.empty((n, n), dtype=np.float32)             # a fresh, untouched destination each time (as a caller's would be)
+            t0 = time.perf_counter()
+            _, st = ctx.pairwise(c_h, t_h, metric, dtype="float32", out=host, want_stats=True)
+            wall = (time.perf_counter() - t0) * 1e3
+            if first is None:
+                first = wall
+            del host
+        host = None
+        lines["host_pointer_first_call_ms"] = first
         lines["d2h_ms"] = wall - st["total_ms"]
         lines["d2h_bytes"] = int(need)
         lines["d2h_gb_per_s"] = need / max(1e-9, (wall - st["total_ms"]) * 1e-3) / 1e9
         lines["host_pointer_call_ms"] = wall
         lines["pairs_per_s_pcie_inclusive"] = n * (n - 1) / 2.0 / (wall * 1e-3)
-        del host
     else:
         lines["d2h_ms"] = None
         lines["d2h_note"] = "skipped: not enough host memory for a %d-byte result" % need
