@@ -89,6 +89,10 @@ SIGNATURES = {
 }
 
 _lib = None
+# Set by `python -m phyloligo_amd` (single process) before the first load(): the CLI needs no torch - host-pointer entry
+# points do the copies - and importing it costs ~0.7 s of a 2 - 3 s run.  Only for a process that will never import torch
+# afterwards: torch bundles its own libamdhip64, and a process must hold exactly one HIP runtime.
+PREFER_NO_TORCH = False
 
 
 def load():
@@ -101,7 +105,7 @@ def load():
         raise ImportError(
             "phyloligo_amd: %s is missing -- build it (make -C phyloligo_amd/csrc, needs hipcc). "
             "There is no CPU fallback." % LIB_PATH)
-    if "torch" not in sys.modules:
+    if "torch" not in sys.modules and not PREFER_NO_TORCH:
         try:
             import torch  # noqa: F401
         except ImportError:

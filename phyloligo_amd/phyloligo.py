@@ -57,7 +57,7 @@ def read_fasta_device(genome):
     """The same records through the on-device parser: (seq CUDA uint8, offsets CUDA int64[n+1], titles), or None when
     the file has the one construct that parser leaves to the host (tabs on sequence lines) or is empty."""
     from ._lib import PhyloligoError, PO_EUNSUPPORTED
-    if os.path.getsize(genome) == 0:
+    if os.path.getsize(genome) == 0 or "torch" not in sys.modules:      # the device buffers of this path are torch tensors
         return None
     try:
         return api.fasta_index_dev(_context(), genome)

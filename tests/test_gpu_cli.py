@@ -206,3 +206,33 @@ def test_multi_gpu_cli_rehearsal(tmp_path, ranks):
         assert out.stdout.count("Computing Pairwise distances") == 1            # rank 0 speaks
         assert open(ref, "rb").read() == open(got, "rb").read(), (metric, large)
         assert open(str(ref) + ".freq", "rb").read() == open(str(got) + ".freq", "rb").read()
+
+
+def test_cli_process_runs_without_torch(fasta, tmp_path):
+    """`python -m phyloligo_amd` as one process needs no torch (numpy + the host-pointer entry points of the C ABI): same
+    bytes as the in-process run, and torch is never imported (0.7 s of a 2 - 3 s run at 50 000 contigs)."""
+    import subprocess
+    import sys
+    from phyloligo_amd import phyloligo as P
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path, g = fasta
+    ref, got = tmp_path / "ref.mat", tmp_path / "got.mat"
+    args = ["-i", path, "-k", "4", "-d", "JSD", "--method", "joblib"]
+    assert P.main(args + ["-o", str(ref)]) == 0
+    code = ("import sys, runpy\n"
+            "sys.argv = ['phyloligo_amd'] + %r\n"
+            "try:\n    runpy.run_module('phyloligo_amd', run_name='__main__')\n"
+            "except SystemExit as e:\n    assert e.code in (0, None)\n"
+            "print('TORCH_IMPORTED' if 'torch' in sys.modules else 'NO_TORCH')\n") % (args + ["-o", str(got)],)
+    env = dict(os.environ, PYTHONPATH=root)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "NO_TORCH" in out.stdout and "TORCH_IMPORTED" not in out.stdout
+    assert open(ref, "rb").read() == open(got, "rb").read()
+    raw_ref, raw_got = tmp_path / "ref.f32", tmp_path / "got.f32"
+    assert P.main(args + ["--large", "memmap", "-o", str(raw_ref)]) == 0
+    out = subprocess.run([sys.executable, "-m", "phyloligo_amd"] + args + ["--large", "memmap", "-o", str(raw_got)],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert open(raw_ref, "rb").read() == open(raw_got, "rb").read()
