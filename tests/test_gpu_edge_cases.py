@@ -163,3 +163,24 @@ def test_jsd_table_kernel_covers_counts_up_to_127(ctx):
     assert not np.array_equal(table, general)                    # two different kernels did run
     freq = po.counts_to_frequencies(counts.astype(np.int64), totals.astype(np.int64))
     np.testing.assert_allclose(table, po.pairwise_block(freq, "JSD"), rtol=RTOL, atol=ATOL)
+
+
+def test_trim_gives_workspaces_back_and_calls_keep_working():
+    """po_ctx_trim frees every grown device workspace (the materialised Kendall operand included); the next call
+    allocates again and gives the same bits; a call for another metric releases a pair-dot operand above 1 GB by itself."""
+    import torch
+    import phyloligo_amd as pa
+    rng = np.random.default_rng(9)
+    counts = rng.integers(0, 30, size=(700, 256)).astype(np.uint32)
+    totals = counts.sum(axis=1).astype(np.uint64)
+    with pa.Context(0) as ctx:
+        free0 = torch.cuda.mem_get_info(0)[0]
+        want = {m: ctx.pairwise(counts, totals, m) for m in ("KT", "JSD", "BC", "Eucl", "SC")}
+        used = free0 - torch.cuda.mem_get_info(0)[0]
+        assert used > 0
+        ctx.trim()
+        assert torch.cuda.mem_get_info(0)[0] >= free0 - (8 << 20)          # everything but crumbs (table, flags) is back
+        for m, w in want.items():
+            assert np.array_equal(ctx.pairwise(counts, totals, m), w, equal_nan=True), m
+        ctx.trim()
+        ctx.trim()                                                          # idempotent
