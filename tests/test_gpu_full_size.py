@@ -100,9 +100,11 @@ def test_full_size_rank_metrics(ctx, metric, diag, lo, hi):
 
 
 @pytest.mark.parametrize("pattern,strand,seed", [("1111", "both", 50001), ("11011011", "both", 50005), ("1111", "plus", 50001),
-                                                  ("1101", "both", 50001), ("111111", "minus", 50001)])
+                                                  ("1101", "both", 50001), ("111111", "minus", 50001), ("1101", "minus", 50001),
+                                                  ("1101" + "0" * 36 + "1", "both", 50001)])
 def test_full_size_profiles(ctx, pattern, strand, seed):
-    """Stage 1 on the whole 50 000-contig assembly (fast path for the forward-word cases, general path for the others):
+    """Stage 1 on the whole 50 000-contig assembly (register-string fast path for every strand mode of the short patterns,
+    two histograms per wave for the non-palindromic `both`; 128-bit rolling windows on the general path for the 41-wide seed):
     row sums are the totals, the totals are the window counts the reference's arithmetic gives, '-s both' profiles are
     reverse-complement symmetric, and 150 contigs drawn over the whole range equal the oracle bit for bit."""
     import torch
