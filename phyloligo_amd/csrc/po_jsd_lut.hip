@@ -17,6 +17,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 constexpr int TM = 128, TN = 128;
@@ -134,13 +136,20 @@ __global__ __launch_bounds__(64 * TM / RW, 4) void jsd_lut_rows_kernel(po_tile_a
     const uint32_t lb = 2 * lane;
     const uint32_t tbase = po_lds_addr(tab);
     const uint32_t kmax = A.dim - 1;                                             // dim is a multiple of 8 (zero padded words)
+    // (operand pointers advance by one word row per step, clamped at the last word: scalar adds, no 64-bit multiplies and no
+    // vector address arithmetic in the loop; the table's LDS base goes onto the two column terms, not onto the 16 row terms -
+    // the scalar unit issued half as many instructions as the vector unit before: SQ_INSTS_SALU 3.2e9 against 6.0e9)
     uint2 bq[kPF];
 #pragma unroll
     for (int q = 0; q < kPF; ++q) bq[q] = *reinterpret_cast<const uint2*>(pb + (uint64_t)min((uint32_t)q, kmax) * A.npad + lb);
+    const uint32_t* pb_pf = pb + (uint64_t)min((uint32_t)kPF, kmax) * A.npad;    // the word the next refill of the ring reads
+    const uint32_t* pa_nx = pa + (uint64_t)min(1u, kmax) * A.npad;              // the word whose row counts are requested next
     AV a_cur = rows_vec<RW>::load(pa);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a_cur) :: "memory");
     __syncthreads();                                                             // the table is in LDS
-    for (uint32_t k0 = 0; k0 < A.dim; k0 += kPF) {
+    // kPF words per round; `clamp` (the last two rounds only) keeps the operand pointers on the last word row
+    auto round = [&](uint32_t k0, auto clamp_tag) {
+        constexpr bool CLAMP = decltype(clamp_tag)::value;
 #pragma unroll
         for (int q = 0; q < kPF; ++q) {
             const uint32_t k = k0 + q;
@@ -148,19 +157,57 @@ __global__ __launch_bounds__(64 * TM / RW, 4) void jsd_lut_rows_kernel(po_tile_a
 #pragma unroll
                 for (int r = 0; r < RW; ++r) { acc[r][0] *= 2.0; acc[r][1] *= 2.0; }
             }
-            AV a_next = rows_vec<RW>::load(pa + (uint64_t)min(k + 1, kmax) * A.npad);
-            const uint32_t b0 = bq[q].x, b1 = bq[q].y;
-            bq[q] = *reinterpret_cast<const uint2*>(pb + (uint64_t)min(k + kPF, kmax) * A.npad + lb);
-#pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                const uint32_t ar = a_cur[r] + tbase;                            // scalar add
-                acc[r][0] += po_lds_read_f64(ar + b0);
-                acc[r][1] += po_lds_read_f64(ar + b1);
+            AV a_next = rows_vec<RW>::load(pa_nx);
+            if (!CLAMP || k + 2 <= kmax) pa_nx += A.npad;
+            const uint32_t b0 = bq[q].x + tbase, b1 = bq[q].y + tbase;
+            bq[q] = *reinterpret_cast<const uint2*>(pb_pf + lb);
+            if (!CLAMP || k + kPF + 1 <= kmax) pb_pf += A.npad;
+            // Groups of four lookups (two rows), two groups in flight.  The instruction stream of a group is written out: four address
+            // adds, four lookups, ONE counted wait (everything but the four lookups just issued is back), the four float64 adds of
+            // the previous group.  Left to the compiler the same work carried a wait in front of almost every add (23 - 32 per word);
+            // every instruction, a wait included, takes an issue slot of its in-order wave, and this loop is bound by issue slots.
+            // (The scalar load of the next word's row counts is also counted by lgkmcnt and returns out of order: it can only make a
+            // counted wait wait longer, never shorter.)
+            double tg[2][4];
+#define PO_JSD_ISSUE4(NW, G)                                                                                                   \
+            asm volatile("v_add_u32 %4, %8, %10\n\tv_add_u32 %5, %8, %11\n\tv_add_u32 %6, %9, %10\n\tv_add_u32 %7, %9, %11\n\t"     \
+                         "ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7"                    \
+                         : "=&v"(NW[0]), "=&v"(NW[1]), "=&v"(NW[2]), "=&v"(NW[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)      \
+                         : "s"(a_cur[2 * (G)]), "s"(a_cur[2 * (G) + 1]), "v"(b0), "v"(b1) : "memory")
+#define PO_JSD_ISSUE4_ADD4(NW, G, OD, H)                                                                                        \
+            asm volatile("v_add_u32 %4, %12, %14\n\tv_add_u32 %5, %12, %15\n\tv_add_u32 %6, %13, %14\n\tv_add_u32 %7, %13, %15\n\t" \
+                         "ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\t"                \
+                         "s_waitcnt lgkmcnt(4)\n\t"                                                                              \
+                         "v_add_f64 %8, %8, %16\n\tv_add_f64 %9, %9, %17\n\tv_add_f64 %10, %10, %18\n\tv_add_f64 %11, %11, %19"     \
+                         : "=&v"(NW[0]), "=&v"(NW[1]), "=&v"(NW[2]), "=&v"(NW[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3),      \
+                           "+v"(acc[2 * (H)][0]), "+v"(acc[2 * (H)][1]), "+v"(acc[2 * (H) + 1][0]), "+v"(acc[2 * (H) + 1][1])        \
+                         : "s"(a_cur[2 * (G)]), "s"(a_cur[2 * (G) + 1]), "v"(b0), "v"(b1),                                           \
+                           "v"(OD[0]), "v"(OD[1]), "v"(OD[2]), "v"(OD[3]) : "memory")
+            {
+                uint32_t t0, t1, t2, t3;
+                PO_JSD_ISSUE4(tg[0], 0);
+                PO_JSD_ISSUE4_ADD4(tg[1], 1, tg[0], 0);
+                PO_JSD_ISSUE4_ADD4(tg[0], 2, tg[1], 1);
+                PO_JSD_ISSUE4_ADD4(tg[1], 3, tg[0], 2);
+                PO_JSD_ISSUE4_ADD4(tg[0], 4, tg[1], 3);
+                PO_JSD_ISSUE4_ADD4(tg[1], 5, tg[0], 4);
+                PO_JSD_ISSUE4_ADD4(tg[0], 6, tg[1], 5);
+                PO_JSD_ISSUE4_ADD4(tg[1], 7, tg[0], 6);
+                // the last group: everything is back behind the wait for the scalar load below
+                asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                             "v_add_f64 %0, %0, %5\n\tv_add_f64 %1, %1, %6\n\tv_add_f64 %2, %2, %7\n\tv_add_f64 %3, %3, %8"
+                             : "+v"(acc[14][0]), "+v"(acc[14][1]), "+v"(acc[15][0]), "+v"(acc[15][1]), "+s"(a_next)
+                             : "v"(tg[1][0]), "v"(tg[1][1]), "v"(tg[1][2]), "v"(tg[1][3]) : "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a_next) :: "memory");
+#undef PO_JSD_ISSUE4
+#undef PO_JSD_ISSUE4_ADD4
+            static_assert(RW == 16, "the eight groups above are written for 16 rows per wave");
             a_cur = a_next;
         }
-    }
+    };
+    uint32_t k0 = 0;
+    for (; k0 + 2 * kPF < A.dim; k0 += kPF) round(k0, std::false_type{});       // every pointer step stays inside the matrix
+    for (; k0 < A.dim; k0 += kPF) round(k0, std::true_type{});
     if (A.dbl_at != PO_NO_DOUBLING && A.dbl_at >= A.dim) {
 #pragma unroll
         for (int r = 0; r < RW; ++r) { acc[r][0] *= 2.0; acc[r][1] *= 2.0; }
