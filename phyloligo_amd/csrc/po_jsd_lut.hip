@@ -143,68 +143,95 @@ __global__ __launch_bounds__(64 * TM / RW, 4) void jsd_lut_rows_kernel(po_tile_a
 #pragma unroll
     for (int q = 0; q < kPF; ++q) bq[q] = *reinterpret_cast<const uint2*>(pb + (uint64_t)min((uint32_t)q, kmax) * A.npad + lb);
     const uint32_t* pb_pf = pb + (uint64_t)min((uint32_t)kPF, kmax) * A.npad;    // the word the next refill of the ring reads
-    const uint32_t* pa_nx = pa + (uint64_t)min(1u, kmax) * A.npad;              // the word whose row counts are requested next
-    AV a_cur = rows_vec<RW>::load(pa);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a_cur) :: "memory");
+    const uint32_t* pa_nx = pa + (uint64_t)min(2u, kmax) * A.npad;              // the word whose row counts are requested next
+    AV a_c0 = rows_vec<RW>::load(pa);                                            // words are taken in pairs: one wait for the scalar
+    AV a_c1 = rows_vec<RW>::load(pa + (uint64_t)min(1u, kmax) * A.npad);         // loads (a full drain of lgkmcnt) per 64 lookups
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a_c0), "+s"(a_c1) :: "memory");
     __syncthreads();                                                             // the table is in LDS
-    // kPF words per round; `clamp` (the last two rounds only) keeps the operand pointers on the last word row
-    auto round = [&](uint32_t k0, auto clamp_tag) {
-        constexpr bool CLAMP = decltype(clamp_tag)::value;
+
+    // Groups of four lookups (two rows), two groups in flight.  The instruction stream of a group is written out: four address
+    // adds, four lookups, ONE counted wait (everything but the four lookups just issued is back), the four float64 adds of
+    // the previous group.  Left to the compiler the same work carried a wait in front of almost every add (23 - 32 per word);
+    // every instruction, a wait included, takes an issue slot of its in-order wave, and this loop is bound by issue slots.
+    // (The scalar loads of the next words' row counts are also counted by lgkmcnt and return out of order: they can only make
+    // a counted wait wait longer, never shorter.)
+    // One asm statement per pair of words (64 lookups per lane): nothing of the compiler's sits between the groups.
+    // operand names: a<r> / e<r> row counts of the two words (scalar), b0 b1 / d0 d1 their column terms, c<2r+e> the accumulators,
+    // n<i> / m<i> the two groups of lookup results in flight, t<i> address scratch
+#define PO_G_ISSUE(W, T, RA, RB, B0, B1)                                                                  \
+    "v_add_u32 %[t0], %[" #W #RA "], %[" #B0 "]\n\tv_add_u32 %[t1], %[" #W #RA "], %[" #B1 "]\n\t"          \
+    "v_add_u32 %[t2], %[" #W #RB "], %[" #B0 "]\n\tv_add_u32 %[t3], %[" #W #RB "], %[" #B1 "]\n\t"          \
+    "ds_read_b64 %[" #T "0], %[t0]\n\tds_read_b64 %[" #T "1], %[t1]\n\tds_read_b64 %[" #T "2], %[t2]\n\tds_read_b64 %[" #T "3], %[t3]\n\t"
+#define PO_G_ADD(T, C0, C1, C2, C3)                                                                        \
+    "v_add_f64 %[c" #C0 "], %[c" #C0 "], %[" #T "0]\n\tv_add_f64 %[c" #C1 "], %[c" #C1 "], %[" #T "1]\n\t"    \
+    "v_add_f64 %[c" #C2 "], %[c" #C2 "], %[" #T "2]\n\tv_add_f64 %[c" #C3 "], %[c" #C3 "], %[" #T "3]\n\t"
+#define PO_G_WAIT4 "s_waitcnt lgkmcnt(4)\n\t"
+    // eight groups of one word; PREV: the accumulators of the group in flight when the word starts (PO_G_NONE for the first word)
+#define PO_G_NONE
+#define PO_G_WORD(W, B0, B1, PREV)                                                                         \
+    PO_G_ISSUE(W, n, 0, 1, B0, B1) PREV                                                                    \
+    PO_G_ISSUE(W, m, 2, 3, B0, B1) PO_G_WAIT4 PO_G_ADD(n, 0, 1, 2, 3)                                        \
+    PO_G_ISSUE(W, n, 4, 5, B0, B1) PO_G_WAIT4 PO_G_ADD(m, 4, 5, 6, 7)                                        \
+    PO_G_ISSUE(W, m, 6, 7, B0, B1) PO_G_WAIT4 PO_G_ADD(n, 8, 9, 10, 11)                                      \
+    PO_G_ISSUE(W, n, 8, 9, B0, B1) PO_G_WAIT4 PO_G_ADD(m, 12, 13, 14, 15)                                    \
+    PO_G_ISSUE(W, m, 10, 11, B0, B1) PO_G_WAIT4 PO_G_ADD(n, 16, 17, 18, 19)                                  \
+    PO_G_ISSUE(W, n, 12, 13, B0, B1) PO_G_WAIT4 PO_G_ADD(m, 20, 21, 22, 23)                                  \
+    PO_G_ISSUE(W, m, 14, 15, B0, B1) PO_G_WAIT4 PO_G_ADD(n, 24, 25, 26, 27)
+#define PO_G_ROWS(W, V) [W##0] "s"(V[0]), [W##1] "s"(V[1]), [W##2] "s"(V[2]), [W##3] "s"(V[3]), [W##4] "s"(V[4]), [W##5] "s"(V[5]),     \
+    [W##6] "s"(V[6]), [W##7] "s"(V[7]), [W##8] "s"(V[8]), [W##9] "s"(V[9]), [W##10] "s"(V[10]), [W##11] "s"(V[11]),                  \
+    [W##12] "s"(V[12]), [W##13] "s"(V[13]), [W##14] "s"(V[14]), [W##15] "s"(V[15])
+#define PO_G_ACC(R) [c##R] "+v"(accf[R])
+    static_assert(RW == 16 && kPF == 4, "the group chains below are written for 16 rows per wave and rounds of four words");
+    auto doubling = [&](uint32_t k) {                                            // folded operands (po_fold.hip); dbl_at is a multiple of 8
+        if (k == A.dbl_at) {
 #pragma unroll
-        for (int q = 0; q < kPF; ++q) {
-            const uint32_t k = k0 + q;
-            if (k == A.dbl_at) {                                                 // folded operands (po_fold.hip)
-#pragma unroll
-                for (int r = 0; r < RW; ++r) { acc[r][0] *= 2.0; acc[r][1] *= 2.0; }
-            }
-            AV a_next = rows_vec<RW>::load(pa_nx);
-            if (!CLAMP || k + 2 <= kmax) pa_nx += A.npad;
-            const uint32_t b0 = bq[q].x + tbase, b1 = bq[q].y + tbase;
-            bq[q] = *reinterpret_cast<const uint2*>(pb_pf + lb);
-            if (!CLAMP || k + kPF + 1 <= kmax) pb_pf += A.npad;
-            // Groups of four lookups (two rows), two groups in flight.  The instruction stream of a group is written out: four address
-            // adds, four lookups, ONE counted wait (everything but the four lookups just issued is back), the four float64 adds of
-            // the previous group.  Left to the compiler the same work carried a wait in front of almost every add (23 - 32 per word);
-            // every instruction, a wait included, takes an issue slot of its in-order wave, and this loop is bound by issue slots.
-            // (The scalar load of the next word's row counts is also counted by lgkmcnt and returns out of order: it can only make a
-            // counted wait wait longer, never shorter.)
-            double tg[2][4];
-#define PO_JSD_ISSUE4(NW, G)                                                                                                   \
-            asm volatile("v_add_u32 %4, %8, %10\n\tv_add_u32 %5, %8, %11\n\tv_add_u32 %6, %9, %10\n\tv_add_u32 %7, %9, %11\n\t"     \
-                         "ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7"                    \
-                         : "=&v"(NW[0]), "=&v"(NW[1]), "=&v"(NW[2]), "=&v"(NW[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)      \
-                         : "s"(a_cur[2 * (G)]), "s"(a_cur[2 * (G) + 1]), "v"(b0), "v"(b1) : "memory")
-#define PO_JSD_ISSUE4_ADD4(NW, G, OD, H)                                                                                        \
-            asm volatile("v_add_u32 %4, %12, %14\n\tv_add_u32 %5, %12, %15\n\tv_add_u32 %6, %13, %14\n\tv_add_u32 %7, %13, %15\n\t" \
-                         "ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\t"                \
-                         "s_waitcnt lgkmcnt(4)\n\t"                                                                              \
-                         "v_add_f64 %8, %8, %16\n\tv_add_f64 %9, %9, %17\n\tv_add_f64 %10, %10, %18\n\tv_add_f64 %11, %11, %19"     \
-                         : "=&v"(NW[0]), "=&v"(NW[1]), "=&v"(NW[2]), "=&v"(NW[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3),      \
-                           "+v"(acc[2 * (H)][0]), "+v"(acc[2 * (H)][1]), "+v"(acc[2 * (H) + 1][0]), "+v"(acc[2 * (H) + 1][1])        \
-                         : "s"(a_cur[2 * (G)]), "s"(a_cur[2 * (G) + 1]), "v"(b0), "v"(b1),                                           \
-                           "v"(OD[0]), "v"(OD[1]), "v"(OD[2]), "v"(OD[3]) : "memory")
-            {
-                uint32_t t0, t1, t2, t3;
-                PO_JSD_ISSUE4(tg[0], 0);
-                PO_JSD_ISSUE4_ADD4(tg[1], 1, tg[0], 0);
-                PO_JSD_ISSUE4_ADD4(tg[0], 2, tg[1], 1);
-                PO_JSD_ISSUE4_ADD4(tg[1], 3, tg[0], 2);
-                PO_JSD_ISSUE4_ADD4(tg[0], 4, tg[1], 3);
-                PO_JSD_ISSUE4_ADD4(tg[1], 5, tg[0], 4);
-                PO_JSD_ISSUE4_ADD4(tg[0], 6, tg[1], 5);
-                PO_JSD_ISSUE4_ADD4(tg[1], 7, tg[0], 6);
-                // the last group: everything is back behind the wait for the scalar load below
-                asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                             "v_add_f64 %0, %0, %5\n\tv_add_f64 %1, %1, %6\n\tv_add_f64 %2, %2, %7\n\tv_add_f64 %3, %3, %8"
-                             : "+v"(acc[14][0]), "+v"(acc[14][1]), "+v"(acc[15][0]), "+v"(acc[15][1]), "+s"(a_next)
-                             : "v"(tg[1][0]), "v"(tg[1][1]), "v"(tg[1][2]), "v"(tg[1][3]) : "memory");
-            }
-#undef PO_JSD_ISSUE4
-#undef PO_JSD_ISSUE4_ADD4
-            static_assert(RW == 16, "the eight groups above are written for 16 rows per wave");
-            a_cur = a_next;
+            for (int r = 0; r < RW; ++r) { acc[r][0] *= 2.0; acc[r][1] *= 2.0; }
         }
     };
+    // two words (k, k + 1) per step; `clamp` (the last two rounds only) keeps the operand pointers on the last word row
+    auto pair_of_words = [&](uint32_t k, int q, auto clamp_tag) {
+        constexpr bool CLAMP = decltype(clamp_tag)::value;
+        doubling(k);
+        AV a_n0 = rows_vec<RW>::load(pa_nx);
+        if (!CLAMP || k + 3 <= kmax) pa_nx += A.npad;
+        AV a_n1 = rows_vec<RW>::load(pa_nx);
+        if (!CLAMP || k + 4 <= kmax) pa_nx += A.npad;
+        const uint32_t b0 = bq[q].x + tbase, b1 = bq[q].y + tbase, c0 = bq[q + 1].x + tbase, c1 = bq[q + 1].y + tbase;
+        bq[q] = *reinterpret_cast<const uint2*>(pb_pf + lb);
+        if (!CLAMP || k + kPF + 1 <= kmax) pb_pf += A.npad;
+        bq[q + 1] = *reinterpret_cast<const uint2*>(pb_pf + lb);
+        if (!CLAMP || k + kPF + 2 <= kmax) pb_pf += A.npad;
+        double n0, n1, n2, n3, m0, m1, m2, m3;
+        uint32_t t0, t1, t2, t3;
+        double* accf = &acc[0][0];                        // c<2r+e> = acc[r][e]
+        // word k, then word k + 1 without a drain (dbl_at is even: no doubling can fall between the two): the first group of the
+        // second word is issued before the last group of the first one is accumulated; the very last group is accumulated behind
+        // the wait for the scalar loads of the next pair (lgkmcnt(0): everything is back)
+        asm volatile(PO_G_WORD(a, b0, b1, PO_G_NONE)
+                     PO_G_WORD(e, d0, d1, PO_G_WAIT4 PO_G_ADD(m, 28, 29, 30, 31))
+                     "s_waitcnt lgkmcnt(0)\n\t" PO_G_ADD(m, 28, 29, 30, 31)
+                     : PO_G_ACC(0), PO_G_ACC(1), PO_G_ACC(2), PO_G_ACC(3), PO_G_ACC(4), PO_G_ACC(5), PO_G_ACC(6), PO_G_ACC(7),
+                       PO_G_ACC(8), PO_G_ACC(9), PO_G_ACC(10), PO_G_ACC(11), PO_G_ACC(12), PO_G_ACC(13), PO_G_ACC(14), PO_G_ACC(15),
+                       PO_G_ACC(16), PO_G_ACC(17), PO_G_ACC(18), PO_G_ACC(19), PO_G_ACC(20), PO_G_ACC(21), PO_G_ACC(22), PO_G_ACC(23),
+                       PO_G_ACC(24), PO_G_ACC(25), PO_G_ACC(26), PO_G_ACC(27), PO_G_ACC(28), PO_G_ACC(29), PO_G_ACC(30), PO_G_ACC(31),
+                       [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3), [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2), [m3] "=&v"(m3),
+                       [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), "+s"(a_n0), "+s"(a_n1)
+                     : PO_G_ROWS(a, a_c0), PO_G_ROWS(e, a_c1), [b0] "v"(b0), [b1] "v"(b1), [d0] "v"(c0), [d1] "v"(c1)
+                     : "memory");
+        a_c0 = a_n0;
+        a_c1 = a_n1;
+    };
+    auto round = [&](uint32_t k0, auto clamp_tag) {
+        pair_of_words(k0, 0, clamp_tag);
+        pair_of_words(k0 + 2, 2, clamp_tag);
+    };
+#undef PO_G_ISSUE
+#undef PO_G_ADD
+#undef PO_G_WAIT4
+#undef PO_G_NONE
+#undef PO_G_WORD
+#undef PO_G_ROWS
+#undef PO_G_ACC
     uint32_t k0 = 0;
     for (; k0 + 2 * kPF < A.dim; k0 += kPF) round(k0, std::false_type{});       // every pointer step stays inside the matrix
     for (; k0 < A.dim; k0 += kPF) round(k0, std::true_type{});
