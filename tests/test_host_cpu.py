@@ -176,3 +176,22 @@ def test_fasta_parallel_segments_equal_sequential_semantics():
     assert int(offsets[-1]) == sum(len(s) for s in seqs) == seq.shape[0]
     assert seq.tobytes() == b"".join(seqs)
     assert np.array_equal(np.diff(offsets.astype(np.int64)), np.array([len(s) for s in seqs]))
+
+
+def test_container_is_sized_and_zero_before_the_rows_arrive(tmp_path):
+    """_reserve_file: the float32 container has its final size (blocks allocated where the filesystem can) and reads as
+    zeros, exactly like the truncated file it replaces (reference: numpy.memmap(mode='w+'), phyloligo.py:413)."""
+    path = str(tmp_path / "m.f32")
+    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
+    try:
+        P._reserve_file(fd, 3 * 1000 * 4)
+        P._reserve_file(fd, 0)                       # n = 0: an empty container, no error
+    finally:
+        os.close(fd)
+    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
+    try:
+        P._reserve_file(fd, 1 << 20)
+    finally:
+        os.close(fd)
+    assert os.path.getsize(path) == 1 << 20
+    assert not np.fromfile(path, dtype=np.uint8).any()
