@@ -19,9 +19,11 @@
 // no float64 log instruction, so ln s is a 512-interval table reduction done in the ALU:
 //   s = 2^e m,  j = top 9 mantissa bits,  r = m*invc[j] - 1  (|r| <= 2^-10, one fma),
 //   ln s = (e*ln2 + logc[j]) + (r - r^2/2 + r^3/3)                  (truncation < 2^-42 = 2.3e-13)
-// The {invc, logc} pairs sit in LDS replicated 8x (64 KiB; lanes tx and tx+8 of a 16-lane read group share
-// a copy, so a lookup costs 1.5 LDS passes on average - the LDS is far from busy in this kernel, the
-// vector ALU is not, and the finer table saves one float64 FMA per word and pair).
+// The {invc, logc} pairs sit in LDS replicated 4x (32 KiB; the four lanes of a 16-lane read group with the same tx & 3
+// share a copy: measured 7.97 LDS cycles per wave-lookup against 4.58 for 16 conflict-free copies, which would be 128 KiB -
+// tools/ubench/lds_b128_lookup.hip; two workgroups per CU need the table twice).
+// (v_frexp_mant_f64 instead of the AND-OR + register-pair move that isolate the mantissa - 4.6 against 6.6 issue cycles in
+// isolation, bit-identical results with 2 invc in the table - measured 65.0 ms against 62.2 in this kernel: not used.)
 #include "po_tiles.h"
 
 #include <math.h>
@@ -33,7 +35,7 @@ constexpr int TM = 128, TN = 128;     // tile of pairs per workgroup
 constexpr int KC = 8;                 // words staged per step
 constexpr int kTabEntries = 512;
 constexpr int kTabCopies = 4;
-constexpr int kTabBytes = kTabEntries * kTabCopies * 16;   // 64 KiB
+constexpr int kTabBytes = kTabEntries * kTabCopies * 16;   // 32 KiB
 constexpr int kStageDoubles = KC * (TM + TN);           // one buffer
 constexpr double LN2 = 0.693147180559945309417232121458;
 
@@ -61,7 +63,7 @@ __device__ __forceinline__ void load_frag(const double* s, int k, uint32_t tx, u
     }
 }
 
-// two pairs (a, b[0]) and (a, b[1]): sum, table address (9 top mantissa bits -> 128-byte row, this lane's
+// two pairs (a, b[0]) and (a, b[1]): sum, table address (9 top mantissa bits -> 64-byte row, this lane's
 // 16-byte copy), table read {invc, logc - 1023 ln2}
 __device__ __forceinline__ void jsd_issue(const JsdConsts& C, double a, const double* b, double (&psum)[2], double2 (&pte)[2]) {
 #pragma unroll
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void valu_tile_kernel
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
 
     if (METRIC == PO_JSD) {
-        const uint4* src = reinterpret_cast<const uint4*>(logtab);       // already replicated, 64 KiB
+        const uint4* src = reinterpret_cast<const uint4*>(logtab);       // already replicated, 32 KiB
         uint4* dst = reinterpret_cast<uint4*>(tab);
         for (uint32_t v = t; v < kTabBytes / 16; v += NT) dst[v] = src[v];
     }
@@ -257,7 +259,7 @@ int launch_metric(po_ctx* ctx, const po_tile_args& a, const unsigned long long* 
 }  // namespace
 
 // Log table for the 512 mantissa intervals [1 + j/512, 1 + (j+1)/512): {invc, -ln(invc) - 1023 ln2} with
-// invc = 1/midpoint, each entry replicated 8x so that copy c of entry j sits at byte j*128 + c*16:
+// invc = 1/midpoint, each entry replicated 4x so that copy c of entry j sits at byte j*64 + c*16:
 // s = 2^(eb-1023) m, ln s = eb ln2 + (logc - 1023 ln2) + log1p(m invc - 1).
 int po_logtab_init(po_ctx* ctx) {
     if (ctx->logtab_ready) return PO_OK;
