@@ -47,6 +47,12 @@ struct CountParams {
     uint32_t two_hist;     // -s both with a pattern that is NOT its own mirror image, fast path available: every wave keeps two
                            // histograms, forward words of the pattern and forward words of the REVERSED pattern (= the
                            // minus-strand words relabelled, see the fast path)
+    uint32_t marg;         // -s both, spaced pattern of at most 4 positions that is not its own mirror image: the kernel counts the
+                           // CONTIGUOUS window (window = k = W, dim = 4^W, symmetric mode: one LDS atomic per start, as cheap as
+                           // `1111`) and the write-out sums the 4^(W-k') windows that spell each spaced word (a window counts iff all
+                           // its W bases are A/C/G/T, phyloligo.py:601-631, so the spaced profile IS a marginal of the contiguous
+                           // one); src_shift / mask / dst_shift / nruns stay those of the spaced pattern, out_dim = 4^k'
+    uint32_t out_dim;
     int strand;
     uint32_t n_seqs;
     uint64_t total_bytes;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
     // LDS: the histograms of the workgroup's waves first (each aligned to its own size, so that a bin address is an OR),
     // then per wave the staged digits, the byte -> digit table and two slots (junction word, group total)
     constexpr uint32_t kAuxWords = kStage / 4 + 64 + 4;
-    const uint32_t HD = (MODE == 2 && P.two_hist) ? 2u * P.dim : P.dim;      // histogram words per wave
+    const uint32_t HD = ((MODE == 2 && P.two_hist) || P.marg) ? 2u * P.dim : P.dim;      // histogram words per wave
     uint32_t* mine = smem + (LDS_HIST ? waves_per_block * HD : 0) + wave * kAuxWords;
     uint8_t* codes = reinterpret_cast<uint8_t*>(mine);            // [kStage]
     uint8_t* dtab = reinterpret_cast<uint8_t*>(mine + kStage / 4); // [256] byte -> digit
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
     if (multi) __syncthreads();
     if (LDS_HIST && wave == lead) {
         __builtin_amdgcn_wave_barrier();
-        uint32_t* row = counts + (uint64_t)rec * P.dim;
+        uint32_t* row = counts + (uint64_t)rec * (P.marg ? P.out_dim : P.dim);
         const uint32_t mid_word = P.sym ? mid_slot[0] : 0xFFFFFFFFu;
         if (whole && rec_chunks > 1 && lane == 0) totals[rec] = mid_slot[1];
         const bool le = fast_done || force_le;
@@ -623,6 +629,33 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
             const uint32_t r = (((b & 0x55555555u) << 1) | (((b >> 1) & 0x55555555u) ^ 0x55555555u)) & (P.dim - 1u);
             return hist[d] + hist[r] + (d == mid_word ? 1u : 0u);
         };
+        if (P.marg) {
+            // contiguous windows -> spaced words: every window x (both strands: hist[x] + hist[rc(x)], + 1 for the junction's
+            // self-mirrored window) is added to the spaced word it spells, in a second LDS array behind the histogram
+            uint32_t* outh = hist + P.dim;                        // [out_dim], zeroed with the histogram
+            const uint32_t cmaskw = 0x55555555u & (P.dim - 1u);
+            for (uint32_t h = lane; h < P.dim; h += 64) {
+                const uint32_t d = le ? digits_reversed(h, P.k) : h;                       // the window, first base highest
+                // slot of its reverse complement rc(d) = digits reversed, each complemented: rc(d) itself, or digits_reversed(rc(d)) = d ^ c
+                const uint32_t hr = le ? (d ^ cmaskw) : (digits_reversed(d, P.k) ^ cmaskw);
+                const uint32_t v = hist[h] + hist[hr] + (d == mid_word ? 1u : 0u);
+                uint32_t word = 0;
+                for (uint32_t r = 0; r < P.nruns; ++r) word |= ((d >> P.src_shift[r]) & P.mask[r]) << P.dst_shift[r];
+                if (v) atomicAdd(&outh[word], v);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (whole) {
+                for (uint32_t d0 = lane * 4; d0 < P.out_dim; d0 += 256) {
+                    if (d0 + 4 <= P.out_dim) *reinterpret_cast<uint4*>(row + d0) = *reinterpret_cast<const uint4*>(outh + d0);
+                    else for (uint32_t d = d0; d < P.out_dim; ++d) row[d] = outh[d];
+                }
+            } else {
+                for (uint32_t d = lane; d < P.out_dim; d += 64) {
+                    const uint32_t v = outh[d];
+                    if (v) atomicAdd(&row[d], v);
+                }
+            }
+        } else
         if (le) {
             // the histogram is indexed by the digit-reversed word: outputs d0..d0+3 differ in their last digit = the first
             // of the reversed word; the mirror window's word, reversed, is d with every digit complemented: one aligned quad.
@@ -719,9 +752,21 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     P.total_bytes = total_bytes;
 
     const bool lds_hist = pat.dim <= kMaxLdsBins;
+    // -s both, spaced pattern of at most 4 positions, not its own mirror image (1101, 1011): count contiguous windows,
+    // marginalise at the write-out - `1101 both` 79.2 -> 50.0 us at C2 (two histograms with two atomics per start before).
+    // Five positions measured WORSE than two histograms (10011 both 145 us, 11101 both 133 us against 68 us for the contiguous
+    // 11111: 1 024 windows per record to fold, 16 per lane): the write-out has to stay small against the 2 016 starts of a chunk.
+    if (strand == PO_STRAND_BOTH && !palindromic && pat.window <= 4 && pat.window > pat.k) {
+        P.marg = 1u;
+        P.out_dim = pat.dim;
+        P.k = pat.window;
+        P.dim = 1u << (2 * pat.window);
+        P.patbits = (1ull << pat.window) - 1ull;
+        P.sym = 1u;
+    }
     // -s both, pattern not its own mirror image, fast path available (window <= 16, at most 4 runs): two histograms per wave
     P.two_hist = (strand == PO_STRAND_BOTH && !P.sym && lds_hist && 2 * pat.window <= 32 && pat.nruns <= 4 && pat.dim <= 4096) ? 1u : 0u;
-    const size_t per_wave = kStage + 256 + 16 + (lds_hist ? (size_t)pat.dim * 4 * (P.two_hist ? 2 : 1) : 0);
+    const size_t per_wave = kStage + 256 + 16 + (lds_hist ? (size_t)P.dim * 4 * ((P.two_hist || P.marg) ? 2 : 1) : 0);
     uint32_t wpb = (uint32_t)((80u << 10) / per_wave);                // waves per workgroup within 80 KiB of LDS
     wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);                          // up to 4 consecutive chunks of one record share a flush (8 and 16 measured slower)
     const size_t shmem = per_wave * wpb;
@@ -737,7 +782,7 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     int lrc = PO_OK;
     // contiguous k-mer: one run that takes the low 2k bits as they are (the reverse register then holds exactly 2W = 2k bits)
     const bool simple = pat.nruns == 1 && pat.src_shift[0] == 0 && pat.dst_shift[0] == 0 && pat.window == pat.k;
-    const int runs = width == 2 ? 0 : (simple ? -1 : (pat.nruns <= 4 ? (int)pat.nruns : 0));
+    const int runs = width == 2 ? 0 : ((simple || P.marg) ? -1 : (pat.nruns <= 4 ? (int)pat.nruns : 0));
 #define PO_COUNT_RUNS(L, N, M, R) if (runs == R) lrc = launch(count_kernel<L, N, M, R>);
 #define PO_COUNT_CASE(L, N, M)                                                                                  \
     if (lds_hist == L && width == N && mode == M) {                                                             \

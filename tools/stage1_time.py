@@ -20,7 +20,8 @@ def best(dseq, doff, pattern, strand, reps=5):
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 configs = (("1111", "both"), ("1111", "plus"), ("11011011", "both"), ("1101", "both"), ("111111", "both"), ("111111", "minus"),
-           ("1111", "minus"), ("1101", "minus"), ("110100111", "both"))
+           ("1111", "minus"), ("1101", "minus"), ("110100111", "both"), ("1011", "both"), ("10011", "both"), ("11101", "both"),
+           ("11111", "both"))
 if which not in ("all", "ragged"):
     configs = tuple(c for c in configs if "%s_%s" % c == which)
 if which == "ragged":
