@@ -61,16 +61,22 @@ __global__ __launch_bounds__(256) void prep_counts_kernel(const uint32_t* __rest
 // empty, or if any count in the matrix exceeds what the table covers.
 // The table identity needs sum_w count = total for every record (what count2freq guarantees); a caller-supplied
 // total that disagrees with its counts shows up as wsum = sum_w count/total != 1 and sends the block to the general kernel.
+// clsk[b] = {1/n, 2 ln n} of that total: the two constants of the tile kernel's epilogue, computed once per block of records here
+// instead of once per wave and tile there (a float64 logarithm and a division are ~200 vector instructions).
 __global__ __launch_bounds__(128) void classify_kernel(const unsigned long long* __restrict__ totals, uint64_t n,
                                                        const uint32_t* __restrict__ maxcount,
                                                        const double* __restrict__ wsum,
-                                                       unsigned long long* __restrict__ cls) {
+                                                       unsigned long long* __restrict__ cls, double2* __restrict__ clsk) {
     const uint64_t r = (uint64_t)blockIdx.x * 128 + threadIdx.x;
     const uint64_t first = (uint64_t)blockIdx.x * 128;
     const unsigned long long ref = totals[first];                     // first < n by construction of the grid
     const bool ok = (r >= n) || (totals[r] == ref && fabs(wsum[r] - 1.0) < 1e-9);
     const int all = __syncthreads_and(ok ? 1 : 0);
-    if (threadIdx.x == 0) cls[blockIdx.x] = (all && ref > 0 && 2u * *maxcount < (uint32_t)kLutEntries) ? ref : 0ull;
+    if (threadIdx.x == 0) {
+        const bool table = all && ref > 0 && 2u * *maxcount < (uint32_t)kLutEntries;
+        cls[blockIdx.x] = table ? ref : 0ull;
+        clsk[blockIdx.x] = table ? make_double2(1.0 / (double)ref, 2.0 * log((double)ref)) : make_double2(0.0, 0.0);
+    }
 }
 
 // the table as the tile kernels want it in LDS: entry x replicated 32 times (copy c at x*32 + c)
@@ -109,7 +115,8 @@ template <> struct rows_vec<16> {
 template <typename OUT, int RW>
 __global__ __launch_bounds__(64 * TM / RW, 4) void jsd_lut_rows_kernel(po_tile_args A, const uint32_t* __restrict__ ct,
                                                               const uint32_t* __restrict__ ctb, const double* __restrict__ lut,
-                                                              const unsigned long long* __restrict__ cls) {
+                                                              const unsigned long long* __restrict__ cls,
+                                                              const double2* __restrict__ clsk) {
     typedef typename rows_vec<RW>::type AV;
     constexpr uint32_t NT = 64 * TM / RW, NW = TM / RW;
     constexpr int kPF = 4;                                                       // words of column counts in flight per lane
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(64 * TM / RW, 4) void jsd_lut_rows_kernel(po_tile_a
     const uint32_t t = threadIdx.x, lane = t & 63;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
     uint32_t ti, tj;
-    po_tile_coords(A, TM, blockIdx.x, ti, tj);
+    po_tile_coords(A, TM, blockIdx.x, ti, tj);     // (a per-launch table of the coordinates instead measured 0.3 % - not worth a launch)
     const unsigned long long ntot = cls[ti];
     if (ntot == 0 || cls[tj] != ntot) return;                                    // valu_tile_kernel<JSD> owns this tile
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
@@ -240,30 +247,82 @@ __global__ __launch_bounds__(64 * TM / RW, 4) void jsd_lut_rows_kernel(po_tile_a
         for (int r = 0; r < RW; ++r) { acc[r][0] *= 2.0; acc[r][1] *= 2.0; }
     }
 
-    // ---- epilogue: JSD = 1/2 (E_i + E_j - S) + ln 2,  S = Tsum/n - 2 ln n  (same operations, same order as the kernel above) ----
-    const double inv_n = 1.0 / (double)ntot;
-    const double two_ln_n = 2.0 * log((double)ntot);
+    // ---- epilogue: JSD = 1/2 (E_i + E_j - S) + ln 2,  S = Tsum/n - 2 ln n ----
+    // Like the loop this part is paid in issue slots (its stores are asynchronous): the two constants of the class come from
+    // classify_kernel, and tiles in the interior of the block - all but the last tile row / column - take a path without
+    // per-lane bounds tests (uniform 64-bit row bases + 32-bit lane offsets, the diagonal fix on diagonal tiles only).
+    const double2 kk = clsk[ti];
+    const double inv_n = kk.x, two_ln_n = kk.y;
     const double* st0 = A.rowstat;
     const uint64_t jc = j0 + 2 * lane;
+    const uint64_t ib = i0 + RW * wv;                                            // first row of the wave's block
     const double ej0 = st0[min(jc, A.npad - 1)], ej1 = st0[min(jc + 1, A.npad - 1)];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-        const uint64_t i = i0 + RW * wv + r;
-        const double ei = st0[i];
-        double v0 = fmax(0.5 * (ei + ej0 - fma(acc[r][0], inv_n, -two_ln_n)) + LN2, 0.0);
-        double v1 = fmax(0.5 * (ei + ej1 - fma(acc[r][1], inv_n, -two_ln_n)) + LN2, 0.0);
-        if (i == jc) v0 = 0.0;
-        if (i == jc + 1) v1 = 0.0;
-        acc[r][0] = v0; acc[r][1] = v1;
+        const double ei = st0[ib + r];
+        acc[r][0] = fmax(0.5 * (ei + ej0 - fma(acc[r][0], inv_n, -two_ln_n)) + LN2, 0.0);
+        acc[r][1] = fmax(0.5 * (ei + ej1 - fma(acc[r][1], inv_n, -two_ln_n)) + LN2, 0.0);
     }
-    // the tile itself: a row of it is 1 KiB of one wave-instruction
+    if (ti == tj) {                                                              // metric(x, x) / squareform diagonal
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            if (ib + r == jc) acc[r][0] = 0.0;
+            if (ib + r == jc + 1) acc[r][1] = 0.0;
+        }
+    }
     OUT* out = static_cast<OUT*>(A.out);
+    OUT* mir = static_cast<OUT*>(A.mirror);
+    double* lds = reinterpret_cast<double*>(smem);
     const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
+    const bool mirrors = po_tile_mirrors(A, ti, tj);                             // uniform over the workgroup
+    const bool interior = i0 >= A.row_begin && i0 + TM <= n_rows && j0 >= A.col_begin && j0 + TN <= n_cols &&
+                          ((A.ld_out | (j0 - A.col_begin)) & 1) == 0 && (reinterpret_cast<uintptr_t>(A.out) & (2 * sizeof(OUT) - 1)) == 0 &&
+                          (!mirrors || (((A.ld_mirror | (i0 - A.row_begin)) & 1) == 0 &&
+                                        (reinterpret_cast<uintptr_t>(A.mirror) & (2 * sizeof(OUT) - 1)) == 0));
+    if (interior) {
+        {   // the tile itself: a row of it is 1 KiB (float64) of one wave-instruction
+            char* rowp = reinterpret_cast<char*>(out + (ib - A.row_begin) * A.ld_out + (j0 - A.col_begin));   // uniform
+            const uint32_t loff = 2 * lane * (uint32_t)sizeof(OUT);
+            const uint64_t pitch = A.ld_out * sizeof(OUT);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                po_store2(reinterpret_cast<OUT*>(rowp + loff), acc[r][0], acc[r][1]);
+                rowp += pitch;
+            }
+        }
+        if (!mirrors) return;
+        // the transposed tile, 64 columns at a time through LDS (the table is dead): full 1 KiB row pieces again
+        const uint32_t loff = 2 * lane * (uint32_t)sizeof(OUT);
+        const uint64_t mpitch = A.ld_mirror * sizeof(OUT);
+#pragma unroll
+        for (int q = 0; q < TN / kRowsMirrorCols; ++q) {
+            __syncthreads();                               // the table (q = 0) / the previous round has been read by everybody
+            if ((lane >> 5) == (uint32_t)q) {              // the lanes holding columns [64 q, 64 q + 64)
+                double* w = lds + 2 * (lane & 31) * kMirrorLdsStride + RW * wv;
+#pragma unroll
+                for (int r = 0; r < RW; r += 2) {
+                    *reinterpret_cast<double2*>(w + r) = make_double2(acc[r][0], acc[r + 1][0]);
+                    *reinterpret_cast<double2*>(w + kMirrorLdsStride + r) = make_double2(acc[r][1], acc[r + 1][1]);
+                }
+            }
+            __syncthreads();
+            char* mrow = reinterpret_cast<char*>(mir + (j0 + kRowsMirrorCols * q + wv - A.col_begin) * A.ld_mirror + (i0 - A.row_begin));   // uniform
+            const double* rd = lds + wv * kMirrorLdsStride + 2 * lane;
+#pragma unroll
+            for (int jq = 0; jq < kRowsMirrorCols / (int)NW; ++jq) {             // one wave per transposed row: wv, wv + 8, ...
+                const double2 w = *reinterpret_cast<const double2*>(rd + jq * (int)NW * kMirrorLdsStride);
+                po_store2(reinterpret_cast<OUT*>(mrow + loff), w.x, w.y);
+                mrow += NW * mpitch;
+            }
+        }
+        return;
+    }
+    // ---- tiles on the edge of the block: every bound tested ----
     const bool vec_out = (A.ld_out & 1) == 0 && ((j0 - A.col_begin) & 1) == 0 &&
                          (reinterpret_cast<uintptr_t>(A.out) & (2 * sizeof(OUT) - 1)) == 0 && j0 >= A.col_begin;
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-        const uint64_t i = i0 + RW * wv + r;
+        const uint64_t i = ib + r;
         if (i < A.row_begin || i >= n_rows) continue;
         OUT* row = out + (i - A.row_begin) * A.ld_out;
         if (vec_out && jc + 1 < n_cols) {
@@ -273,16 +332,12 @@ __global__ __launch_bounds__(64 * TM / RW, 4) void jsd_lut_rows_kernel(po_tile_a
             if (jc + 1 >= A.col_begin && jc + 1 < n_cols) po_out_store(&row[jc + 1 - A.col_begin], (OUT)acc[r][1]);
         }
     }
-    if (!po_tile_mirrors(A, ti, tj)) return;                                     // uniform over the workgroup
-    // the transposed tile, 64 columns at a time through LDS (the table is dead): full 1 KiB row pieces again
-    OUT* mir = static_cast<OUT*>(A.mirror);
-    double* lds = reinterpret_cast<double*>(smem);
+    if (!mirrors) return;
     const bool vec_mir = (A.ld_mirror & 1) == 0 && ((i0 - A.row_begin) & 1) == 0 &&
                          (reinterpret_cast<uintptr_t>(A.mirror) & (2 * sizeof(OUT) - 1)) == 0 && i0 >= A.row_begin;
-#pragma unroll
     for (int q = 0; q < TN / kRowsMirrorCols; ++q) {
-        __syncthreads();                                   // the table (q = 0) / the previous round has been read by everybody
-        if ((lane >> 5) == (uint32_t)q) {                  // the lanes holding columns [64 q, 64 q + 64)
+        __syncthreads();
+        if ((lane >> 5) == (uint32_t)q) {
             const uint32_t c = 2 * (lane & 31);
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
@@ -291,7 +346,7 @@ __global__ __launch_bounds__(64 * TM / RW, 4) void jsd_lut_rows_kernel(po_tile_a
             }
         }
         __syncthreads();
-        for (uint32_t jq = wv; jq < kRowsMirrorCols; jq += NW) {                 // one wave per transposed row
+        for (uint32_t jq = wv; jq < kRowsMirrorCols; jq += NW) {
             const uint64_t j = j0 + kRowsMirrorCols * q + jq;
             if (j < A.col_begin || j >= n_cols) continue;
             const double2 w = *reinterpret_cast<const double2*>(lds + jq * kMirrorLdsStride + 2 * lane);
@@ -314,7 +369,8 @@ size_t po_jsd_lut_workspace(uint64_t n, uint32_t dim) {
     return po_round_up(dim, 8) * npad * sizeof(uint32_t)      // Ct
            + po_round_up(npad / 128 * sizeof(unsigned long long), 16)   // cls
            + kLutBytes + 256                                    // replicated T + maxcount
-           + po_round_up(dim, 8) * npad * sizeof(uint32_t);     // Ct with the lanes' table copies baked in (rows kernel)
+           + po_round_up(dim, 8) * npad * sizeof(uint32_t)      // Ct with the lanes' table copies baked in (rows kernel)
+           + npad / 128 * sizeof(double2);                      // clsk
 }
 
 // Builds Ct, the table and the tile classes in ws (layout as sized above); returns the class array.
@@ -328,6 +384,7 @@ int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t
     double* lut = reinterpret_cast<double*>(base);
     uint32_t* maxcount = reinterpret_cast<uint32_t*>(base + kLutBytes);
     uint32_t* ctb = reinterpret_cast<uint32_t*>(base + kLutBytes + 256);
+    double2* clsk = reinterpret_cast<double2*>(base + kLutBytes + 256 + po_round_up(dim, 8) * npad * sizeof(uint32_t));
     PO_HIP(hipMemsetAsync(maxcount, 0, sizeof(uint32_t), ctx->stream));
     dim3 grid((uint32_t)(npad / 64), (dim + 63) / 64);
     hipLaunchKernelGGL(prep_counts_kernel, grid, dim3(256), 0, ctx->stream, d_counts, n, dim, npad, ct, ctb, maxcount);
@@ -335,7 +392,7 @@ int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t
     hipLaunchKernelGGL(lut_table_kernel, dim3(kLutEntries), dim3(32), 0, ctx->stream, lut);
     PO_CHECK_LAUNCH("lut_table_kernel");
     hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, ctx->stream,
-                       reinterpret_cast<const unsigned long long*>(d_totals), n, maxcount, d_wsum, cls);
+                       reinterpret_cast<const unsigned long long*>(d_totals), n, maxcount, d_wsum, cls, clsk);
     PO_CHECK_LAUNCH("classify_kernel");
     *cls_out = cls;
     return PO_OK;
@@ -349,6 +406,7 @@ int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, cons
     base += po_round_up(a.npad / 128 * sizeof(unsigned long long), 16);
     const double* lut = reinterpret_cast<const double*>(base);
     const uint32_t* ctb = reinterpret_cast<const uint32_t*>(base + kLutBytes + 256);
+    const double2* clsk = reinterpret_cast<const double2*>(base + kLutBytes + 256 + po_round_up(a.dim, 8) * a.npad * sizeof(uint32_t));
     (void)n;
     const uint64_t nblocks = po_tile_count(a, TM);
     if (tiles) *tiles += nblocks;
@@ -358,10 +416,10 @@ int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, cons
     const size_t shmem = kRowsLdsBytes;
     if (a.out_f32) {
         PO_SHMEM(ctx, (jsd_lut_rows_kernel<float, RWL>), shmem);
-        hipLaunchKernelGGL((jsd_lut_rows_kernel<float, RWL>), dim3((uint32_t)nblocks), dim3(64 * TM / RWL), shmem, ctx->stream, a, ct, ctb, lut, cls);
+        hipLaunchKernelGGL((jsd_lut_rows_kernel<float, RWL>), dim3((uint32_t)nblocks), dim3(64 * TM / RWL), shmem, ctx->stream, a, ct, ctb, lut, cls, clsk);
     } else {
         PO_SHMEM(ctx, (jsd_lut_rows_kernel<double, RWL>), shmem);
-        hipLaunchKernelGGL((jsd_lut_rows_kernel<double, RWL>), dim3((uint32_t)nblocks), dim3(64 * TM / RWL), shmem, ctx->stream, a, ct, ctb, lut, cls);
+        hipLaunchKernelGGL((jsd_lut_rows_kernel<double, RWL>), dim3((uint32_t)nblocks), dim3(64 * TM / RWL), shmem, ctx->stream, a, ct, ctb, lut, cls, clsk);
     }
     PO_CHECK_LAUNCH("jsd_lut_rows_kernel");
     return PO_OK;
