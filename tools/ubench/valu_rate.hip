@@ -54,6 +54,8 @@ __global__ void kd(double* out, int iters) {
             if (OP == 3) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(x) : "v"(u));
             if (OP == 4) asm volatile("v_frexp_mant_f64 %0, %0" : "+v"(x));
             if (OP == 5) asm volatile("v_rsq_f64 %0, %0" : "+v"(x));
+            if (OP == 6) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(x) : "v"(c));       // 64-bit integer add (fixed-point accumulate?)
+            if (OP == 7) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(x) : "v"(c), "v"(d));
         }
     }
     double s = 0; for (int i = 0; i < 8; ++i) s += a[i];
@@ -76,7 +78,7 @@ int main() {
         run<12>("v_mov_b32", d, w); run<13>("v_lshrrev_b32", d, w); run<14>("v_med3_i32", d, w);
         double* dd = reinterpret_cast<double*>(d);
         rund<0>("v_fma_f64", dd, w); rund<1>("v_add_f64", dd, w); rund<2>("v_mul_f64", dd, w); rund<3>("v_cvt_f64_u32", dd, w);
-        rund<4>("v_frexp_mant_f64", dd, w); rund<5>("v_rsq_f64", dd, w);
+        rund<4>("v_frexp_mant_f64", dd, w); rund<5>("v_rsq_f64", dd, w); rund<6>("v_lshl_add_u64", dd, w); rund<7>("v_fmac_f64", dd, w);
     }
     return 0;
 }
