@@ -305,8 +305,11 @@ def main_distributed(params):
             print("Writing frequency matrix")
             api.write_mat_text(params.out_freq_file, ctx.frequencies(counts, totals).cpu().numpy())
         if rank == 0:
-            with open(params.out_file, "wb") as f:
-                f.truncate(n * n * 4)
+            fd0 = os.open(params.out_file, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
+            try:
+                _reserve_file(fd0, n * n * 4)
+            finally:
+                os.close(fd0)
         tdist.barrier()
         fd = os.open(params.out_file, os.O_RDWR)
 
