@@ -242,7 +242,17 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 / KT extras in config.other_configs")
     ap.add_argument("--no-complete-rows", action="store_true", help="N>1: skip timing the optional row-completing exchange")
     ap.add_argument("--no-path-lines", action="store_true", help="skip config.path_lines (H2D, D2H, container write, end-to-end CLI wall)")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("PO_BENCH_LAUNCH_TIMEOUT", "3000")),
+                    help="--gpus N>1 started plainly: seconds after which the launcher kills its ranks")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with N > 1 and no WORLD_SIZE: this process becomes the launcher (it has imported neither torch
+    # nor the library, so it has not touched a GPU) and starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    # as a fresh child; rank 0 of the child prints the JSON line straight to our stdout.  The reference starts its own workers
+    # the same way (joblib Parallel over gen_even_slices, bin/phyloligo.py:386-390, :424).
+    from phyloligo_amd import launch
+    if launch.needs_launcher(args.gpus):
+        return launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)], sys.argv[1:], timeout_s=args.launch_timeout)
 
     import torch
     import phyloligo_amd as pa
@@ -271,7 +281,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:               # started under torch.distributed.run with a different --nproc-per-node
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (plain `python bench.py --gpus N` starts its own ranks)" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
     cdev = "cpu" if rehearsal else dev            # where small collectives live (gloo in rehearsal)
 
@@ -351,7 +362,7 @@ def main():
     rank_kernel_ms = [kernel_ms]
     complete_rows_ms = None
     if dist is not None:
-        g = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        g = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(dist.get_world_size())]
         dist.all_gather(g, torch.tensor([kernel_ms], dtype=torch.float64, device=cdev))
         rank_kernel_ms = [float(x.item()) for x in g]
         if not args.no_complete_rows and not rehearsal and world > 1:
@@ -435,6 +446,12 @@ def main():
             result["value_general_kernel_note"] = ("same matrix through valu_tile_kernel<JSD> only; `value` is the integer-sum table "
                                                     "kernel, which fixed-length synthetic contigs qualify for")
         if world > 1 or dist is not None:
+            # the roofline of the dominant kernel on EVERY rank: its own pair evaluations x bytes per pair / its own HIP-event time
+            per_rank = []
+            for r, ms_r in enumerate(rank_kernel_ms):
+                rp = float(plan.pair_evaluations(r))
+                per_rank.append(dict(hbm_roofline(bytes_per_pair * rp, ms_r), rank=r, pairs=rp, kernel_ms=ms_r))
+            result["roofline_per_rank"] = per_rank
             result["config"]["multi_gpu"] = {
                 "ranks_seen": ranks_seen, "backend": "gloo (rehearsal on one GPU)" if rehearsal else "nccl (RCCL)",
                 "allgather_ms": allgather_ms, "allgather_bytes": int(counts.numel() * 4 + totals.numel() * 8),
@@ -506,4 +523,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

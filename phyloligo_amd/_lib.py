@@ -13,7 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libphyloligo_amd.so")
 # Experiments only (tools/exp/ab.sh): load a variant build from somewhere else instead of overwriting the product
 # library in place.  The name starts with PO_ so that bench.py records it among config.env_knobs.
+# A variable left over in a shell must not silently swap the library under tests or benchmarks: it is honoured
+# only together with the explicit opt-in PO_ALLOW_VARIANT=1 (which ab.sh sets); without it the import fails loudly.
 if os.environ.get("PO_LIB_PATH"):
+    if os.environ.get("PO_ALLOW_VARIANT") != "1":
+        raise ImportError("phyloligo_amd: PO_LIB_PATH=%s is set without PO_ALLOW_VARIANT=1 -- refusing to load a variant "
+                          "library in place of the product library (unset PO_LIB_PATH, or opt in for an experiment)"
+                          % os.environ["PO_LIB_PATH"])
     LIB_PATH = os.path.abspath(os.environ["PO_LIB_PATH"])
     sys.stderr.write("phyloligo_amd: PO_LIB_PATH set -- loading the VARIANT library %s\n" % LIB_PATH)
 

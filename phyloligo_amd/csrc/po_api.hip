@@ -113,6 +113,10 @@ extern "C" int po_ctx_trim(po_ctx* ctx) {
     po_buf* all[] = {&ctx->ws_freq, &ctx->ws_rowstat, &ctx->ws_aux, &ctx->ws_io, &ctx->ws_fold, &ctx->ws_fold_src, &ctx->ws_recover,
                      &ctx->ws_pairdot, &ctx->ws_pq, &ctx->ws_thermo, &ctx->ws_fasta};
     for (po_buf* b : all) buf_free(b);
+    buf_free(&ctx->ws_logtab);              // rebuilt by po_logtab_init on the next JSD call
+    ctx->logtab_ready = false;
+    for (int i = 0; i < 2; ++i)             // the pinned ring of the host-pointer forms (2 x 32 MB), re-created on demand
+        if (ctx->h_stage[i]) { (void)hipHostFree(ctx->h_stage[i]); ctx->h_stage[i] = nullptr; }
     ctx->pq_key = ~0ull;                    // cached tables went with their buffers
     ctx->fold_dim = ctx->fold_gran = ctx->fold_dim_f = ctx->fold_dbl_at = 0;
     ctx->fasta_data = nullptr;
@@ -148,6 +152,7 @@ int po_buf_reserve(po_ctx* ctx, po_buf* b, size_t bytes) {
     hipError_t e = hipMalloc(&b->p, want);
     if (e != hipSuccess) {
         b->p = nullptr;
+        (void)hipGetLastError();               // the failed allocation must not surface again at the next launch check
         po_set_error("device allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
         return PO_ENOMEM;
     }
@@ -437,7 +442,12 @@ extern "C" int po_profile_distances(po_ctx* ctx, const uint32_t* counts, const u
 // ---- stage 2 -------------------------------------------------------------------------------
 static const uint64_t kPadRows = 128;   // tile edge of the VALU / Gram kernels
 
-static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
+// with_operand: also reserve the materialised Kendall pair-sign operand (up to 24 GB, FP4, folded layout).  Only
+// po_pairwise_reserve asks for that - it cannot know the flags of the calls to come; a compute call reserves exactly what its
+// own path uses inside po_launch_kt_pairdot_prep (PO_FLAG_NO_PAIRDOT / NO_TABLE_PATH / int8 operands / the panel kernel never
+// touch this buffer, and must not fail with PO_ENOMEM because of it).  A failed reservation of the operand is not an error
+// here either: the call that needs it falls back to the panel kernel.
+static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric, bool with_operand) {
     const uint64_t npad = po_round_up(n ? n : 1, kPadRows);
     int rc = po_buf_reserve(ctx, &ctx->ws_rowstat, 4 * npad * sizeof(double));
     if (rc) return rc;
@@ -456,14 +466,11 @@ static int reserve_pairwise(po_ctx* ctx, uint64_t n, uint32_t dim, int metric) {
         }
         // the materialised pair-sign operand: sized for the reverse-complement folded layout when the word space is 4^k
         // (what `-s both` gives), else for all words; a call that needs more grows it lazily
-        if (po_kt_pairdot_supported(dim)) {
+        if (with_operand && po_kt_pairdot_supported(dim)) {
             const uint32_t selfs = po_fold_selfs(dim);
             const bool fold = selfs != 0xFFFFFFFFu;
             const size_t opb = po_kt_pairdot_operand_bytes(n, dim, fold ? selfs + (dim - selfs) / 2 : dim, fold ? selfs : 0, fold, 1);
-            if (opb <= PO_PAIRDOT_MAX_OPERAND) {
-                rc = po_buf_reserve(ctx, &ctx->ws_pairdot, opb);
-                if (rc) return rc;
-            }
+            if (opb <= PO_PAIRDOT_MAX_OPERAND) (void)po_buf_reserve(ctx, &ctx->ws_pairdot, opb);
         }
     }
     // the pair-dot operand of an earlier Kendall / Bray-Curtis call (up to 24 GB) is dead weight for the other metrics
@@ -493,7 +500,7 @@ extern "C" int po_pairwise_reserve(po_ctx* ctx, uint64_t n, uint32_t dim, int me
     int rc = check_metric(metric);
     if (rc) return rc;
     PO_HIP(hipSetDevice(ctx->device));
-    return reserve_pairwise(ctx, n, dim, metric);
+    return reserve_pairwise(ctx, n, dim, metric, true);
 }
 
 // Exactly one of (d_counts,d_totals) / d_freq is given.  Prepares the working layout once, then
@@ -530,7 +537,7 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
     PO_REQUIRE(d_freq != nullptr || (d_counts != nullptr && d_totals != nullptr), "%s: NULL buffer", who);
     PO_HIP(hipSetDevice(ctx->device));
 
-    rc = reserve_pairwise(ctx, n, dim, metric);
+    rc = reserve_pairwise(ctx, n, dim, metric, false);
     if (rc) return rc;
     const uint64_t npad = po_round_up(n, kPadRows);
     double* ft = static_cast<double*>(ctx->ws_freq.p);
@@ -633,10 +640,13 @@ static int pairwise_core(po_ctx* ctx, const char* who, const uint32_t* d_counts,
         if (kt_mfma && po_kt_pairdot_operand_bytes(n, dim, fold_src ? selfs + n_pairs : dim, selfs, fold_src != nullptr, want_fp4) >
                            PO_PAIRDOT_MAX_OPERAND)
             kt_mfma = false;
+        if (kt_mfma) {
+            rc = po_launch_kt_pairdot_prep(ctx, lessrank, n, dim, npad, fold_src, selfs, n_pairs, want_fp4, &kt_plan);
+            if (rc == PO_ENOMEM) { rc = PO_OK; kt_mfma = false; }    // no room for the operand: the panel / VALU kernel does without
+        }
         kt_panel = !kt_mfma && kt_panel_ok;
         if (kt_panel && fold_src && !po_kt_panel_fold_supported(dim, selfs)) { fold_src = nullptr; folded = false; }
-        if (kt_mfma) rc = po_launch_kt_pairdot_prep(ctx, lessrank, n, dim, npad, fold_src, selfs, n_pairs, want_fp4, &kt_plan);
-        else if (kt_panel) rc = po_launch_kt_panel_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, fold_src, fold_len, selfs, n_pairs, &kt_pplan);
+        if (kt_panel) rc = po_launch_kt_panel_prep(ctx, lessrank, n, dim, npad, ctx->ws_freq.p, fold_src, fold_len, selfs, n_pairs, &kt_pplan);
         if (rc) return rc;
     }
     if (metric == PO_EUCL || (metric == PO_SC && !sc_i8)) {

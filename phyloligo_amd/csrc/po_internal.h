@@ -39,8 +39,8 @@ void po_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
     } while (0)
 
 // ---- context ---------------------------------------------------------------------------
-// A growable device buffer owned by the context (never freed before po_ctx_destroy, so the
-// steady state of repeated calls does no hipMalloc).
+// A growable device buffer owned by the context: it only grows between po_ctx_trim / po_ctx_destroy (and the pair-dot operand
+// is released when a call for another metric follows), so the steady state of repeated calls does no hipMalloc.
 struct po_buf {
     void* p = nullptr;
     size_t cap = 0;

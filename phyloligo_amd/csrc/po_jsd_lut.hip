@@ -142,7 +142,11 @@ __global__ __launch_bounds__(64 * TM / RW, 4) void jsd_lut_rows_kernel(po_tile_a
     const uint32_t* pb = ctb + j0;                                               // + k * npad, + 2 lane
     const uint32_t lb = 2 * lane;
     const uint32_t tbase = po_lds_addr(tab);
-    const uint32_t kmax = A.dim - 1;                                             // dim is a multiple of 8 (zero padded words)
+    // The word loop runs over the zero-padded width D8 (prep_counts_kernel pads Ct / Ctb to whole groups of 8 words; a padded
+    // word looks up T[0 + 0] = 0), NOT over A.dim: a round takes four words, and clamping the operand pointers at the last REAL
+    // word of a width that is not a multiple of 4 would add that word's lookup again for every surplus slot.
+    const uint32_t dim8 = (A.dim + 7u) & ~7u;
+    const uint32_t kmax = dim8 - 1;
     // (operand pointers advance by one word row per step, clamped at the last word: scalar adds, no 64-bit multiplies and no
     // vector address arithmetic in the loop; the table's LDS base goes onto the two column terms, not onto the 16 row terms -
     // the scalar unit issued half as many instructions as the vector unit before: SQ_INSTS_SALU 3.2e9 against 6.0e9)
@@ -240,9 +244,9 @@ __global__ __launch_bounds__(64 * TM / RW, 4) void jsd_lut_rows_kernel(po_tile_a
 #undef PO_G_ROWS
 #undef PO_G_ACC
     uint32_t k0 = 0;
-    for (; k0 + 2 * kPF < A.dim; k0 += kPF) round(k0, std::false_type{});       // every pointer step stays inside the matrix
-    for (; k0 < A.dim; k0 += kPF) round(k0, std::true_type{});
-    if (A.dbl_at != PO_NO_DOUBLING && A.dbl_at >= A.dim) {
+    for (; k0 + 2 * kPF < dim8; k0 += kPF) round(k0, std::false_type{});        // every pointer step stays inside the matrix
+    for (; k0 < dim8; k0 += kPF) round(k0, std::true_type{});
+    if (A.dbl_at != PO_NO_DOUBLING && A.dbl_at >= dim8) {                        // (folded widths are multiples of 8: dim8 == dim)
 #pragma unroll
         for (int r = 0; r < RW; ++r) { acc[r][0] *= 2.0; acc[r][1] *= 2.0; }
     }

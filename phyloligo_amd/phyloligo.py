@@ -235,6 +235,9 @@ def get_cmd(argv=None):
     parser.add_argument("-w", "--workdir", action="store", dest="workdir", default=".", help="working directory")
     parser.add_argument("-p", "--pattern", action="store", dest="pattern", default="1111",
                         help="spaced-word pattern string, only containing 1s and 0s, i.e. '100101001', default='1111'")
+    parser.add_argument("--gpus", action="store", dest="gpus", type=int, default=1,
+                        help="not in the reference: GPUs of this node to use, one process each (python -m phyloligo_amd starts "
+                             "the ranks itself; the analogue of the reference fanning out to -c joblib workers) [default:%(default)d]")
     params = parser.parse_args(argv)
     params.workdir = os.path.abspath(params.workdir)
     return params

@@ -107,3 +107,46 @@ def test_row_blocks_partition():
                 assert lo % 128 == 0 or lo == n
                 covered = hi
             assert covered == n
+
+
+def test_launcher_starts_ranks_relays_output_and_status(tmp_path):
+    """phyloligo_amd.launch.spawn_ranks (what `bench.py --gpus N` and `python -m phyloligo_amd --gpus N` become when started
+    plainly): ranks run as a fresh child process group, write to the launcher's stdout, the return code comes back, a hung
+    job is killed as a group on timeout, and the launcher itself never imports torch.  No GPU involved: the ranks are a
+    tiny script joining a gloo group."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rank_script = tmp_path / "rank.py"
+    rank_script.write_text(
+        "import os, sys, time\n"
+        "import torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.ones(1); dist.all_reduce(t)\n"
+        "if sys.argv[1] == 'hang':\n"
+        "    time.sleep(600)\n"
+        "if dist.get_rank() == 0:\n"
+        "    print('RANKS %d ARG %s' % (int(t.item()), sys.argv[1]), flush=True)\n"
+        "dist.destroy_process_group()\n"
+        "sys.exit(3 if sys.argv[1] == 'fail' else 0)\n")
+    driver = ("import sys; sys.path.insert(0, %r)\n"
+              "from phyloligo_amd import launch\n"
+              "assert launch.needs_launcher(2) and not launch.needs_launcher(1)\n"
+              "rc = launch.spawn_ranks(2, [%r], [sys.argv[1]], timeout_s=float(sys.argv[2]))\n"
+              "assert 'torch' not in sys.modules\n"
+              "sys.exit(rc)\n") % (root, str(rank_script))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    ok = subprocess.run([sys.executable, "-c", driver, "fine", "120"], capture_output=True, text=True, timeout=300, env=env)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    assert ok.stdout.count("RANKS 2 ARG fine") == 1
+    bad = subprocess.run([sys.executable, "-c", driver, "fail", "120"], capture_output=True, text=True, timeout=300, env=env)
+    assert bad.returncode != 0
+    t0 = __import__("time").time()
+    hung = subprocess.run([sys.executable, "-c", driver, "hang", "20"], capture_output=True, text=True, timeout=300, env=env)
+    assert hung.returncode == 124 and "killing the process group" in hung.stderr
+    assert __import__("time").time() - t0 < 120
+    # inside a rank (WORLD_SIZE set) nobody launches again
+    env2 = dict(env, WORLD_SIZE="2")
+    chk = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\nfrom phyloligo_amd import launch\n"
+                          "sys.exit(1 if launch.needs_launcher(8) else 0)" % root], env=env2, timeout=60)
+    assert chk.returncode == 0

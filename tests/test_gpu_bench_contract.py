@@ -65,6 +65,32 @@ def test_bench_multi_rank_path_rehearsal():
     assert abs(r["value"] - r["config"]["pairs"] / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
 
 
+def test_bench_launches_its_own_ranks():
+    """plain `python bench.py --gpus 2 ...` - no torchrun on the command line, which is how the driver
+    starts the N = 1 run - becomes a launcher (it has not touched the GPU), starts its ranks as a fresh child process and
+    relays rank 0's single JSON line and the child's return code.  Rehearsal: both ranks share this one GPU over gloo."""
+    env = dict(os.environ, PO_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--contigs", "4096", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["multi_gpu"]["ranks_seen"] == 2 and r["steps"] == 2
+    per = r["roofline_per_rank"]
+    assert [x["rank"] for x in per] == [0, 1]
+    for x in per:
+        assert x["bound"] == "hbm" and x["achieved"] > 0 and abs(x["frac"] - x["achieved"] / x["peak"]) < 1e-12
+        assert x["pairs"] > 0 and x["kernel_ms"] > 0
+    assert abs(sum(x["pairs"] for x in per) - (4096 * 4097 / 2.0)) < 1                  # every pair (and the diagonal) once
+    # a failing child is reported through the return code, not swallowed
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--contigs", "4096", "--steps", "1",
+                          "--warmup", "0", "--metric", "nope"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert bad.returncode != 0
+
+
 def test_bench_default_workloads_are_the_baseline_configs():
     """bench.py --gpus 1 = BASELINE config 2, --gpus N > 1 = BASELINE config 4 (read from the source: running 200 000
     contigs needs more than one GPU)."""

@@ -206,6 +206,15 @@ def test_multi_gpu_cli_rehearsal(tmp_path, ranks):
         assert out.stdout.count("Computing Pairwise distances") == 1            # rank 0 speaks
         assert open(ref, "rb").read() == open(got, "rb").read(), (metric, large)
         assert open(str(ref) + ".freq", "rb").read() == open(str(got) + ".freq", "rb").read()
+        if metric == "Eucl":
+            # the same job started plainly: `python -m phyloligo_amd --gpus N ...` starts its own ranks (phyloligo_amd/launch.py)
+            env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+            got2 = tmp_path / ("plain_" + name)
+            out = subprocess.run([sys.executable, "-m", "phyloligo_amd", "--gpus", str(ranks)] + args + ["-o", str(got2)],
+                                 capture_output=True, text=True, timeout=600, cwd=root, env=env2)
+            assert out.returncode == 0, out.stderr[-3000:]
+            assert out.stdout.count("Computing Pairwise distances") == 1
+            assert open(ref, "rb").read() == open(got2, "rb").read()
 
 
 def test_cli_process_runs_without_torch(fasta, tmp_path):

@@ -184,3 +184,25 @@ def test_trim_gives_workspaces_back_and_calls_keep_working():
             assert np.array_equal(ctx.pairwise(counts, totals, m), w, equal_nan=True), m
         ctx.trim()
         ctx.trim()                                                          # idempotent
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3, 5, 6, 7, 50, 63])
+def test_jsd_table_kernel_widths_not_multiple_of_four(ctx, dim):
+    """jsd_lut_rows_kernel consumes four words per round; with a width that is not a multiple of 4 the
+    surplus slots of the last round must read zero-padded words, not the last real word again.  Equal totals and counts
+    <= 127 put every tile on the table kernel; the general kernel (table_path=False) and the oracle are the checks."""
+    from oracle import phyloligo_oracle as po
+    rng = np.random.default_rng(1000 + dim)
+    n, total = 300, 96
+    counts = rng.multinomial(total, rng.dirichlet(np.ones(dim) * 0.7), size=n).astype(np.uint32)
+    counts[7] = counts[3]                                        # a duplicate pair
+    totals = np.full(n, total, dtype=np.uint64)
+    assert counts.max() <= 127 and np.array_equal(counts.sum(axis=1), totals)
+    got, st = ctx.pairwise(counts, totals, "JSD", want_stats=True)
+    assert st["kernel_id"] == 6                                  # the table kernel took part
+    gen, st2 = ctx.pairwise(counts, totals, "JSD", table_path=False, want_stats=True)
+    assert st2["kernel_id"] == 1
+    np.testing.assert_allclose(got, gen, rtol=1e-9, atol=1e-13)
+    want = po.pairwise_block(po.counts_to_frequencies(counts.astype(np.int64), totals), "JSD")
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-12)
+    assert got[3, 7] < 1e-13 and np.array_equal(got, got.T)

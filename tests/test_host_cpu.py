@@ -4,6 +4,7 @@ the reference's argparse, and compute calls fail loudly without a GPU.  No compu
 import io
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -195,3 +196,12 @@ def test_container_is_sized_and_zero_before_the_rows_arrive(tmp_path):
         os.close(fd)
     assert os.path.getsize(path) == 1 << 20
     assert not np.fromfile(path, dtype=np.uint8).any()
+
+
+def test_scalar_row_loads_are_waited_for_before_use():
+    """jsd_lut_rows_kernel issues s_load_dwordx16 in one asm statement and waits in a later one; the gfx950
+    assembly of the file as built must not touch the destination SGPRs in between (tools/check_scalar_loads.py)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_scalar_loads.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ok" in r.stdout
