@@ -249,6 +249,16 @@ int po_fasta_extract_dev(po_ctx* ctx, const uint8_t* d_data, uint64_t len, uint8
  * between columns, '\n' after each row, "nan"/"inf" spelled as numpy spells them.            */
 int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, uint64_t ld, const char* path, int append);
 
+/* The write side of the raw float32 container of `--large memmap` (bin/phyloligo.py:394-427: row slices assigned into a
+ * numpy.memmap of the output file, :200-217; read back by phyloligo_comparemat.py:16-24 and phyloselect.py:606-614):
+ * `rows` pieces of row_bytes bytes, piece r taken from src + r * src_pitch, go to byte offset file_offset + r * file_pitch
+ * of the OPEN file descriptor fd through up to `threads` parallel pwrite(2) callers (<= 0: 8; never more than the CPUs the
+ * job may use).  Whole rows of the matrix (row_bytes == src_pitch == file_pitch) are written as one contiguous range; a
+ * rectangular block of a multi-GPU work list (some columns of some rows) is one pwrite per row.  Host only: no po_ctx, no
+ * GPU.  Several processes may write disjoint ranges of one file at once.  Returns PO_EIO with the errno text on failure. */
+int po_pwrite_rows(int fd, const void* src, uint64_t rows, uint64_t row_bytes, uint64_t src_pitch,
+                   uint64_t file_offset, uint64_t file_pitch, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,7 @@ SIGNATURES = {
     "po_fasta_scan_dev": (_int, [_vp, _vp, _u64, _c.POINTER(_u64), _c.POINTER(_u64)]),
     "po_fasta_extract_dev": (_int, [_vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     "po_write_mat_text": (_int, [_vp, _u64, _u64, _u64, _cp, _int]),
+    "po_pwrite_rows": (_int, [_int, _vp, _u64, _u64, _u64, _u64, _u64, _int]),
 }
 
 _lib = None

@@ -214,6 +214,57 @@ extern "C" int po_file_read(const char* path, uint8_t* buf, uint64_t len) {
     return PO_OK;
 }
 
+// `rows` pieces of row_bytes bytes, piece r at src + r * src_pitch, to byte offset file_offset + r * file_pitch of an open
+// file: the write side of the raw float32 container (bin/phyloligo.py:394-427 assigns row slices of a numpy.memmap, :200-217).
+// A row block that spans whole rows of the file (row_bytes == both pitches) is one contiguous range, cut into one piece per
+// thread; a block of a tournament work list (columns [c0, c1) of rows [r0, r1), or the transpose of one) is one pwrite per
+// row, the rows dealt out in contiguous runs so that every thread walks the file forwards.  pwrite(2) takes its offset as an
+// argument: the callers share the descriptor and no file position.
+extern "C" int po_pwrite_rows(int fd, const void* src, uint64_t rows, uint64_t row_bytes, uint64_t src_pitch,
+                              uint64_t file_offset, uint64_t file_pitch, int threads) {
+    if (rows == 0 || row_bytes == 0) return PO_OK;
+    if (fd < 0 || !src || src_pitch < row_bytes || file_pitch < row_bytes) {
+        po_set_error("po_pwrite_rows: bad argument (fd %d, row_bytes %llu, pitches %llu / %llu)", fd, (unsigned long long)row_bytes,
+                     (unsigned long long)src_pitch, (unsigned long long)file_pitch);
+        return PO_EINVAL;
+    }
+    const uint8_t* base = static_cast<const uint8_t*>(src);
+    auto put = [&](const uint8_t* p, uint64_t len, uint64_t at) -> int {
+        while (len) {                                              // pwrite may write less than asked
+            const ssize_t w = pwrite(fd, p, len, (off_t)at);
+            if (w < 0) { if (errno == EINTR) continue; return errno ? errno : EIO; }
+            p += w; len -= (uint64_t)w; at += (uint64_t)w;
+        }
+        return 0;
+    };
+    const bool contiguous = row_bytes == src_pitch && row_bytes == file_pitch;
+    const uint64_t total = rows * row_bytes;
+    unsigned nthr = po_host_threads(threads > 0 ? (unsigned)threads : 8u);
+    if (total / (4u << 20) + 1 < nthr) nthr = (unsigned)(total / (4u << 20) + 1);      // at least 4 MiB per thread
+    if (!contiguous && rows < nthr) nthr = (unsigned)rows;
+    std::vector<int> errs(nthr, 0);
+    auto work = [&](unsigned t) {
+        if (contiguous) {
+            const uint64_t per = ((total + nthr - 1) / nthr + 4095u) & ~(uint64_t)4095u;   // page-aligned cuts
+            const uint64_t a = std::min<uint64_t>(total, (uint64_t)t * per), b = std::min<uint64_t>(total, a + per);
+            if (b > a) errs[t] = put(base + a, b - a, file_offset + a);
+            return;
+        }
+        const uint64_t per = (rows + nthr - 1) / nthr;
+        const uint64_t r0 = std::min<uint64_t>(rows, (uint64_t)t * per), r1 = std::min<uint64_t>(rows, r0 + per);
+        for (uint64_t r = r0; r < r1 && !errs[t]; ++r) errs[t] = put(base + r * src_pitch, row_bytes, file_offset + r * file_pitch);
+    };
+    if (nthr <= 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthr; ++t) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    for (int e : errs)
+        if (e) { po_set_error("po_pwrite_rows: pwrite failed: %s", strerror(e)); return PO_EIO; }
+    return PO_OK;
+}
+
 // The copy threads live for the whole call (spawning 8 threads per 32 MB chunk cost ~20 % of the copy): they wait for
 // `ready` to pass their chunk, copy their rows of it and count themselves into `done`; the main thread waits for a
 // chunk's producer, for the copies of the chunk before it (whose staging buffer the next fill overwrites), issues the

@@ -9,12 +9,16 @@
 //   san_host_test mat <rows> <cols> <path>   po_write_mat_text of a generated matrix, read back and compared with snprintf("%.18e")
 //   san_host_test fileread <path>     po_file_read against a plain fread
 //   san_host_test ring <MiB>          po_ring_copy_rows with a producer thread filling the staging buffers
+//   san_host_test pwrite <n> <path>   po_pwrite_rows: an n x n float32 container written as whole-row blocks and as
+//                                     rectangular blocks (+ transposes), read back and compared entry by entry
+#include <fcntl.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <string>
@@ -191,6 +195,40 @@ int main(int argc, char** argv) {
         CHECK(want.empty() || memcmp(have.data(), want.data(), want.size()) == 0);
         CHECK(po_file_read("/nonexistent/file", have.data(), 1) == PO_EIO);
         printf("read %zu bytes\n", want.size());
+        return 0;
+    }
+    if (mode == "pwrite" && argc == 4) {
+        const uint64_t n = strtoull(argv[2], nullptr, 10);
+        CHECK(n >= 8);
+        std::vector<float> m(n * n);
+        for (uint64_t i = 0; i < n * n; ++i) m[i] = (float)(i % 1000003) * 0.25f;
+        FILE* mk = fopen(argv[3], "wb");
+        CHECK(mk != nullptr);
+        fclose(mk);
+        const int fd = open(argv[3], O_RDWR);
+        CHECK(fd >= 0);
+        CHECK(ftruncate(fd, (off_t)(n * n * 4)) == 0);
+        const uint64_t h = n / 2, q = n / 3;
+        // rows [0, h): whole rows, one contiguous range, 5 threads; from a source with the same pitch
+        CHECK(po_pwrite_rows(fd, m.data(), h, n * 4, n * 4, 0, n * 4, 5) == PO_OK);
+        // rows [h, n) x columns [0, q): a rectangular block out of a packed [n - h, q] buffer (what a mirror block is)
+        std::vector<float> blk((n - h) * q);
+        for (uint64_t r = h; r < n; ++r) memcpy(&blk[(r - h) * q], &m[r * n], q * 4);
+        CHECK(po_pwrite_rows(fd, blk.data(), n - h, q * 4, q * 4, h * n * 4, n * 4, 7) == PO_OK);
+        // rows [h, n) x columns [q, n): straight out of the matrix (source pitch = n floats), default thread count
+        CHECK(po_pwrite_rows(fd, &m[h * n + q], n - h, (n - q) * 4, n * 4, (h * n + q) * 4, n * 4, 0) == PO_OK);
+        CHECK(po_pwrite_rows(fd, m.data(), 0, 16, 16, 0, 16, 4) == PO_OK);                 // nothing to do
+        CHECK(po_pwrite_rows(-1, m.data(), 1, 16, 16, 0, 16, 4) == PO_EINVAL);
+        CHECK(po_pwrite_rows(fd, m.data(), 2, 16, 8, 0, 16, 4) == PO_EINVAL);              // pitch below the row
+        close(fd);
+        const int ro = open(argv[3], O_RDONLY);
+        CHECK(ro >= 0);
+        CHECK(po_pwrite_rows(ro, m.data(), 1, 16, 16, 0, 16, 1) == PO_EIO);                // not writable
+        close(ro);
+        std::vector<float> back(n * n);
+        CHECK(po_file_read(argv[3], reinterpret_cast<uint8_t*>(back.data()), n * n * 4) == PO_OK);
+        CHECK(memcmp(back.data(), m.data(), n * n * 4) == 0);
+        printf("pwrite %llu x %llu float32 ok\n", (unsigned long long)n, (unsigned long long)n);
         return 0;
     }
     if (mode == "ring" && argc == 3) {

@@ -10,6 +10,7 @@ HIP kernels of libphyloligo_amd.so (there is no joblib/scoop task farm and no CP
 import argparse
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -17,6 +18,13 @@ from . import api
 from ._lib import METRICS, STRANDS
 
 _ctx = None
+
+
+def _timing(text):
+    """PO_CLI_TIMING=1: phase times on stderr (tools/container_writer_bench.py compares the multi-rank writer with the
+    single-process one); silent otherwise - the reference prints nothing of the kind."""
+    if os.environ.get("PO_CLI_TIMING") == "1":
+        sys.stderr.write("phyloligo_amd timing: %s\n" % text)
 
 
 def _context():
@@ -111,11 +119,35 @@ def _reserve_file(fd, size):
     os.ftruncate(fd, size)
 
 
-def _write_raw_f32(out_file, n, rows, writers=8):
+def _pwrite_rows(fd, host, row0, col0, n, threads=8):
+    """host[R, C] float32 (unit inner stride) -> rows row0.., columns col0.. of the n x n float32 container behind fd
+    (po_pwrite_rows: parallel pwrite in C, no Python per row)."""
+    import ctypes
+    from . import _lib
+    rows, cols = host.shape
+    if rows == 0 or cols == 0:
+        return
+    assert host.dtype == np.float32 and host.strides[1] == 4 and host.strides[0] >= cols * 4
+    _lib.check(_lib.load().po_pwrite_rows(fd, ctypes.c_void_p(host.ctypes.data), rows, cols * 4, host.strides[0],
+                                          (row0 * n + col0) * 4, n * 4, threads))
+
+
+def _bc_memmap_diagonal(buf, lo, hi, empty):
+    """The reference's memmap variant evaluates Bray-Curtis through BC_loc -> phylodist.BC -> pairwise_distances(X, X[s],
+    metric="braycurtis") (bin/phyloligo.py:214-217, core/phylodist.py:76-79), i.e. SciPy cdist: an EMPTY profile against
+    itself is 0/0 = nan there, where the joblib variant (pdist + squareform, :381) has an exact 0 on the diagonal
+    (tests/golden/memmap.npz vs distances.npz).  The container follows the variant it stands for."""
+    for i in empty:
+        if lo <= i < hi:
+            buf[i - lo, i] = np.nan
+
+
+def _write_raw_f32(out_file, n, rows, writers=8, fix=None):
     """The container of compute_distances_memmap (phyloligo.py:394-427): headerless row-major float32[n, n] (:413), the
     file phyloligo_comparemat.py:16-24 and phyloselect.py:606-614 read back.  Row blocks come off the device into
-    one of two reusable host buffers and go to the file with parallel pwrite calls while the next block is computed
-    and copied: no second ndarray, no page faults on a file mapping (numpy.memmap assignment measured ~3 GB/s)."""
+    one of two reusable host buffers and go to the file through po_pwrite_rows (parallel pwrite) on a background thread
+    while the next block is computed and copied: no second ndarray, no page faults on a file mapping (numpy.memmap
+    assignment measured ~3 GB/s).  fix(buf, lo, hi): host-side touch-up of a finished row block before it is written."""
     import concurrent.futures as cf
     fd = os.open(out_file, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
     try:
@@ -124,29 +156,71 @@ def _write_raw_f32(out_file, n, rows, writers=8):
             return
         step = min(n, _row_chunk(n, 4, budget=512 << 20))
         bufs = [np.empty((step, n), dtype=np.float32) for _ in range(2 if step < n else 1)]
-        pending = [[] for _ in bufs]
-
-        def put(view, offset):
-            done = 0
-            while done < len(view):                      # pwrite may write less than asked
-                done += os.pwrite(fd, view[done:], offset + done)
-
-        with cf.ThreadPoolExecutor(max_workers=writers) as pool:
+        pending = [None for _ in bufs]
+        with cf.ThreadPoolExecutor(max_workers=1) as pool:       # one submitter; the parallelism is inside po_pwrite_rows
             for k, lo in enumerate(range(0, n, step)):
                 hi = min(n, lo + step)
                 which = k % len(bufs)
-                for f in pending[which]:                 # the block written from this buffer two rounds ago
-                    f.result()
+                if pending[which] is not None:                   # the block written from this buffer two rounds ago
+                    pending[which].result()
                 buf = bufs[which][:hi - lo]
                 rows(lo, hi, "float32", lo == 0 and hi == n, out=buf)
-                flat = memoryview(buf.reshape(-1)).cast("B")
-                piece = -(-len(flat) // writers)
-                pending[which] = [pool.submit(put, flat[a:a + piece], lo * n * 4 + a) for a in range(0, len(flat), piece)]
-            for fl in pending:
-                for f in fl:
+                if fix is not None:
+                    fix(buf, lo, hi)
+                pending[which] = pool.submit(_pwrite_rows, fd, buf, lo, 0, n, writers)
+            for f in pending:
+                if f is not None:
                     f.result()
     finally:
         os.close(fd)
+
+
+class _BlockWriter:
+    """Device blocks of one rank -> their byte ranges of the shared float32 container (the multi-GPU form of
+    _write_raw_f32): two pinned host buffers; the device-to-host copy of chunk k + 1 runs on a side stream while
+    po_pwrite_rows (parallel pwrite) puts chunk k into the file from a background thread."""
+
+    def __init__(self, fd, n, device, chunk_bytes=256 << 20, writers=8):
+        import concurrent.futures as cf
+        import torch
+        self.torch, self.fd, self.n, self.writers = torch, fd, n, writers
+        self.chunk = chunk_bytes
+        self.stage = [torch.empty(chunk_bytes // 4, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        self.pending = [None, None]
+        self.stream = torch.cuda.Stream(device)
+        self.pool = cf.ThreadPoolExecutor(max_workers=1)
+        self.k = 0
+
+    def put(self, t, row0, col0, fix=None):
+        """t[R, C] float32 on the device -> rows row0.., columns col0.. of the file"""
+        torch = self.torch
+        R, C = t.shape
+        if R == 0 or C == 0:
+            return
+        per = max(1, self.chunk // (C * 4))
+        self.stream.wait_stream(torch.cuda.current_stream(t.device))
+        for a in range(0, R, per):
+            b = min(R, a + per)
+            which = self.k & 1
+            self.k += 1
+            if self.pending[which] is not None:                  # the chunk written from this buffer two rounds ago
+                self.pending[which].result()
+            view = self.stage[which][:(b - a) * C].view(b - a, C)
+            with torch.cuda.stream(self.stream):
+                view.copy_(t[a:b], non_blocking=True)
+            self.stream.synchronize()                            # (the previous chunk is being written meanwhile)
+            host = view.numpy()
+            if fix is not None:
+                fix(host, row0 + a, row0 + b)
+            self.pending[which] = self.pool.submit(_pwrite_rows, self.fd, host, row0 + a, col0, self.n, self.writers)
+
+    def close(self):
+        try:
+            for f in self.pending:
+                if f is not None:
+                    f.result()
+        finally:
+            self.pool.shutdown(wait=True)
 
 
 _SINGLE_CALL_BYTES = 4 << 30      # larger float64 matrices are computed and copied in row blocks
@@ -190,7 +264,12 @@ def compute_distances(mthdrun, large, frequencies, freq_name, out_file, dist, th
                                  symmetric=symmetric, out=out)
 
     if large == "memmap":
-        _write_raw_f32(out_file, n, rows)
+        fix = None
+        if dist == "BC":
+            empty = np.flatnonzero(~np.asarray(frequencies).any(axis=1))
+            if empty.size:
+                fix = lambda buf, lo, hi: _bc_memmap_diagonal(buf, lo, hi, empty)      # noqa: E731
+        _write_raw_f32(out_file, n, rows, fix=fix)
         return None
     if n * n * 8 <= _SINGLE_CALL_BYTES:
         return rows(0, n, "float64", True)
@@ -297,6 +376,7 @@ def main_distributed(params):
     else:
         counts, totals = plan.all_gather_profiles(my_counts, my_totals, tdist)
     say("Computing Pairwise distances")
+    t_dist0 = time.perf_counter()
     dtype = torch.float32 if params.large == "memmap" else torch.float64
     slab, mirrors = plan.allocate(rank, dev, dtype)
     plan.compute(ctx, counts, totals, params.dist, rank, slab, mirrors)
@@ -315,25 +395,26 @@ def main_distributed(params):
                 os.close(fd0)
         tdist.barrier()
         fd = os.open(params.out_file, os.O_RDWR)
+        empty = totals.cpu().numpy() == 0 if params.dist == "BC" else None
 
-        def put_block(t, row0, col0):                           # t[R, C] on the device -> rows row0.., columns col0..
-            per = max(1, (256 << 20) // max(1, t.shape[1] * 4))
-            for a in range(0, t.shape[0], per):
-                h = t[a:a + per].contiguous().cpu().numpy()
-                flat, width = memoryview(h.reshape(-1)).cast("B"), h.shape[1] * 4
-                for r in range(h.shape[0]):
-                    piece, at, done = flat[r * width:(r + 1) * width], ((row0 + a + r) * n + col0) * 4, 0
-                    while done < width:
-                        done += os.pwrite(fd, piece[done:], at + done)
+        def diag_fix(host, a, b):                               # rows [a, b) x columns [lo, hi) of a diagonal block
+            for i in np.flatnonzero(empty[a:b]) + a:
+                host[i - a, i - lo] = np.nan
 
+        writer = _BlockWriter(fd, n, dev)
         try:
             for ((r0, r1), (c0, c1), kind, peer), m in zip(plan.work(rank), mirrors):
-                put_block(slab[r0 - lo:r1 - lo, c0:c1], r0, c0)
+                fix = diag_fix if (kind == "diag" and empty is not None and empty[r0:r1].any()) else None
+                writer.put(slab[r0 - lo:r1 - lo, c0:c1], r0, c0, fix=fix)
                 if m is not None:
-                    put_block(m, c0, r0)
+                    writer.put(m, c0, r0)
         finally:
-            os.close(fd)
+            try:
+                writer.close()
+            finally:
+                os.close(fd)
         tdist.barrier()
+        _timing("rank %d of %d: distances + container %.3f s" % (rank, world, time.perf_counter() - t_dist0))
         tdist.destroy_process_group()
         return 0
     # text matrix: rows have to be complete - the transposed blocks go to the ranks whose rows they belong to
@@ -380,8 +461,10 @@ def main(argv=None):
                                                  params.strand, params.distchunksize, params.threads_max,
                                                  params.workdir)
     print("Computing Pairwise distances")
+    t_dist0 = time.perf_counter()
     res = compute_distances(params.mthdrun, params.large, frequencies, freq_name, params.out_file, params.dist,
                             params.threads_max, params.freqchunksize, params.workdir)
+    _timing("single process: distances%s %.3f s" % (" + container" if params.large == "memmap" else "", time.perf_counter() - t_dist0))
     if params.out_freq_file:
         print("Writing frequency matrix")
         api.write_mat_text(params.out_freq_file, np.asarray(frequencies))

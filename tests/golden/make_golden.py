@@ -250,6 +250,36 @@ def main():
             fa["totals_%s_%s_%s" % (name, pat, strand)] = totals
             fa["freq_%s_%s_%s" % (name, pat, strand)] = freqs
     np.savez_compressed(os.path.join(HERE, "fasta_cases.npz"), **fa)
+    # (6) SURVEY 8f-1: the --large memmap variant through the reference's OWN memmap code (SURVEY 8c
+    # listed it as "not pinnable" because the module needs h5py / scoop to import - the stand-ins above solve that, and
+    # compute_distances_memmap itself needs only numpy + joblib + sklearn).  Frequencies go into a float32 memmap exactly as
+    # compute_frequencies_joblib_memmap fills it (bin/phyloligo.py:903-913: compute_frequency_memmap per record), then
+    # compute_distances_memmap (:394-427) -> euclidean_distances_loc / JSD_loc (:200-207) writes the float32 container.
+    # The bytes of that container are the fixture.  BC_loc / KT_loc / SC_loc are broken in the reference (:209-222): what
+    # they raise is recorded, not worked around.  (n_jobs = 1: loky workers cannot unpickle functions of a module loaded
+    # from a file path under a stand-in name; the workers' row slices are disjoint, so the bytes do not depend on it.)
+    import tempfile
+    mm = {"contigs": dist["contigs"]}
+    with tempfile.TemporaryDirectory() as tmp:
+        for pat, strand in [("1111", "both"), ("1101", "minus")]:
+            key = "%s_%s" % (pat, strand)
+            for metric in ("Eucl", "JSD", "BC", "KT", "SC"):
+                folder = tempfile.mkdtemp(dir=tmp)                 # compute_distances_memmap removes dirname(freq_name) (:426-427)
+                freq_name = os.path.join(folder, "frequencies")
+                fr = np.memmap(freq_name, dtype=np.float32, shape=(len(set48), 4 ** pat.count("1")), mode="w+")
+                for i, sq in enumerate(set48):
+                    ref.compute_frequency_memmap(fr, i, sq, pat, strand)
+                mm["freq32_" + key] = np.array(fr)
+                out = os.path.join(tmp, "dist_%s_%s.f32" % (metric, key))
+                try:
+                    ref.compute_distances_memmap(fr, freq_name, out, metric=metric, n_jobs=1)
+                except Exception as exc:                          # noqa: BLE001 - the reference's own failure is the datum
+                    mm["raises_%s_%s" % (metric, key)] = np.array(["%s: %s" % (type(exc).__name__, exc)], dtype="U")
+                    continue
+                finally:
+                    del fr
+                mm["container_%s_%s" % (metric, key)] = np.fromfile(out, dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "memmap.npz"), **mm)
     print("golden vectors written to", HERE)
 
 

@@ -22,7 +22,8 @@ def test_host_code_under_sanitizers(tmp_path, san):
         p = tmp_path / (name + ".fa")
         p.write_bytes(CASES[name])
         runs.append(["fasta", str(p)])
-    runs += [["bigfasta", "12"], ["mat", "300", "700", str(tmp_path / "m.mat")], ["fileread", str(tmp_path / "m.mat")], ["ring", "20"]]
+    runs += [["bigfasta", "12"], ["mat", "300", "700", str(tmp_path / "m.mat")], ["fileread", str(tmp_path / "m.mat")],
+             ["pwrite", "1501", str(tmp_path / "c.f32")], ["ring", "20"]]
     for args in runs:
         r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (args, r.stderr[-2000:])

@@ -75,6 +75,7 @@ def main():
             run("mat", "2500", "4000", os.path.join(tmp, "big.mat"))  # 10^7 entries through the threaded writer
             run("mat", "3", "5", os.path.join(tmp, "small.mat"))
             run("fileread", os.path.join(tmp, "big.mat"))             # 250 MB through the parallel pread reader
+            run("pwrite", "3001", os.path.join(tmp, "c.f32"))         # 36 MB container: whole-row and rectangular blocks, 1-8 writers
             run("ring", "96")                                         # 96 MiB through the two-buffer copy ring
     print("==== %d failing run(s); sanitizer reports: %s" % (failures, "none" if failures == 0 else "see above"))
     return 1 if failures else 0
