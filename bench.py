@@ -240,6 +240,8 @@ def main():
     ap.add_argument("--pattern", default="1111")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 / KT extras in config.other_configs")
+    ap.add_argument("--no-ragged", action="store_true", help="skip config.ragged_assembly (a real-assembly-like input of the same "
+                                                             "number of contigs through every metric)")
     ap.add_argument("--no-complete-rows", action="store_true", help="N>1: skip timing the optional row-completing exchange")
     ap.add_argument("--no-path-lines", action="store_true", help="skip config.path_lines (H2D, D2H, container write, end-to-end CLI wall)")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("PO_BENCH_LAUNCH_TIMEOUT", "3000")),
@@ -407,6 +409,17 @@ def main():
             res = max((k for k in ("valu", "lds", "mfma") if b.get(k) is not None), key=lambda k: b[k])
             return {"resource": res, "busy": b[res], "all": {k: b.get(k) for k in ("valu", "lds", "mfma")}, "source": busy.get("_source")}
 
+        # The committed counter files name the build they were measured on (tools/pmc_busy.py / pmc_traffic.py write the
+        # library's po_version(), which carries the hash of its sources): counters of another build are flagged, not trusted.
+        from phyloligo_amd import _lib as _polib
+        lib_version = _polib.load().po_version().decode()
+        lib_hash = lib_version.rsplit("src ", 1)[-1] if "src " in lib_version else None
+        stale = []
+        if traffic_all.get("_detail", {}).get("src_hash") != lib_hash:
+            stale.append("profiles/traffic.json (every roofline.traffic): measured on src %s" % traffic_all.get("_detail", {}).get("src_hash"))
+        if busy.get("_src_hash") != lib_hash:
+            stale.append("profiles/pmc_busy.json (every roofline.binding): measured on src %s" % busy.get("_src_hash"))
+
         main_key = {6: "jsd_lut_rows_kernel", 1: "valu_tile_kernel<JSD>", 4: "gram_i8_tile_kernel<1>", 3: "gram_tile_kernel<f64>",
                     7: "bc_sad_tile_kernel", 2: "valu_tile_kernel<BC>", 8: "pairdot_tile_kernel<KT>", 9: "pairdot_tile_kernel<BC>"}.get(main_kernel_id)
         roof = hbm_roofline(bytes_per_pair * rank_pairs, kernel_ms, traffic=traffic if world == 1 else None, traffic_source=traffic_source,
@@ -414,6 +427,9 @@ def main():
                             binding=binding(main_key),
                             note="nominal roof per north_star; the JSD tile kernels are bound by LDS / vector-ALU issue, "
                                  "not by HBM bytes (one table lookup or logarithm per word and pair for 16 B of output), see DESIGN.md section 3")
+        roof["lib_version"] = lib_version
+        roof["counters_stale"] = bool(stale)          # true: `traffic` / `binding` below come from rocprof passes over ANOTHER build
+        roof["counters_stale_what"] = stale
         general = None
         if args.metric == "JSD" and world == 1:      # the same matrix through the general float64-log kernel only
             gms = [step(want_stats=True, table_path=False) for _ in range(2)]
@@ -504,6 +520,56 @@ def main():
             except Exception as exc:             # never let the extras break the headline line
                 others["error"] = repr(exc)
             result["config"]["other_configs"] = others
+        if world == 1 and args.metric == "JSD" and not args.no_ragged:
+            # What a REAL assembly gets: the same number of contigs with log-normal lengths 1 - 200 kb,
+            # four base compositions, N runs, soft-masked stretches and IUPAC codes (synthetic.ragged_assembly; parity of exactly
+            # this input: tests/test_gpu_full_size.py::test_ragged_assembly_*).  No two totals alike: every JSD / BC tile is the
+            # general kernel's, Eucl / SC take two digit planes.  Not part of `value`.
+            try:
+                t0 = time.perf_counter()
+                rseq, roff = synthetic.ragged_assembly(n, seed=2024)
+                gen_s = time.perf_counter() - t0
+                d_rseq = torch.from_numpy(rseq).to(dev)
+                d_roff = torch.from_numpy(roff.astype(np.int64)).to(dev)
+                ctx.count_profiles(d_rseq, d_roff, args.pattern, "both")
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                rc_, rt_ = ctx.count_profiles(d_rseq, d_roff, args.pattern, "both")
+                torch.cuda.synchronize(dev)
+                r_stage1 = (time.perf_counter() - t0) * 1e3
+                rdim = rc_.shape[1]
+                rbpp = 16 + 2 * rdim * 4 / (n - 1)
+                rag = {"workload": "%d contigs, log-normal lengths 1 - 200 kb (%.3f Gb, longest %d), base compositions %s by i %% 4, N runs, "
+                                   "lower case, IUPAC codes (phyloligo_amd.synthetic.ragged_assembly, seed 2024), pattern %s both strands"
+                                   % (n, rseq.size / 1e9, int(np.diff(roff.astype(np.int64)).max()), list(synthetic.SPECIES), args.pattern),
+                       "generate_s": gen_s, "bases": int(rseq.size), "largest_count": int(rc_.max()),
+                       "stage1_ms": r_stage1,
+                       "stage1_roofline": hbm_roofline(rseq.size + n * rdim * 4 + n * 8, r_stage1,
+                                                       note="wall time of po_count_profiles_dev (scan + memset + count_kernel), algorithmic "
+                                                            "bytes = bases + counts + totals (SURVEY 8d)"),
+                       "metrics": {}}
+                del d_rseq
+                for m in ("JSD", "BC", "Eucl", "SC", "KT"):
+                    best = None
+                    for _ in range(3):
+                        _, s2 = ctx.pairwise(rc_, rt_, m, out=slab, want_stats=True)
+                        if best is None or s2["total_ms"] < best["total_ms"]:
+                            best = s2
+                    rag["metrics"][m] = {"ms": best["total_ms"], "kernel_ms": best["kernel_ms"], "prep_ms": best["prep_ms"],
+                                         "pairs_per_s": pairs / (best["total_ms"] * 1e-3), "kernel_id": best["kernel_id"],
+                                         "kernel": KERNEL_NAMES.get(best["kernel_id"]), "rc_folded": best["rc_folded"],
+                                         "roofline": hbm_roofline(rbpp * pairs, best["kernel_ms"],
+                                                                  traffic=traffic_all.get("%s_ragged_n%d_d%d" % (m, n, rdim)))}
+                rag["metrics"]["JSD"]["roofline"]["binding"] = binding("valu_tile_kernel<JSD>")
+                rag["metrics"]["BC"]["roofline"]["binding"] = binding("valu_tile_kernel<BC>")
+                rag["metrics"]["KT"]["roofline"]["binding"] = binding("pairdot_tile_kernel<KT>")
+                result["config"]["ragged_assembly"] = rag
+                result["value_ragged_assembly"] = rag["metrics"]["JSD"]["pairs_per_s"]
+                result["value_ragged_assembly_note"] = ("pairs/s of -d JSD on the ragged assembly (valu_tile_kernel<JSD> owns every tile): the "
+                                                        "rate a real input gets; `value` needs equal word totals")
+                del rc_, rt_
+            except Exception as exc:             # never let the extras break the headline line
+                result["config"]["ragged_assembly"] = {"error": repr(exc)}
         if world == 1 and args.metric == "JSD" and not args.no_path_lines:
             # "stage-1 time, H2D, D2H and .mat writing are reported as separate lines, never hidden" - none of them
             # is part of `value`.  Measured on THIS workload (the C2 assembly when the defaults are used).

@@ -112,7 +112,7 @@ typedef struct po_stats {
 #define PO_KERNEL_LUT_JSD 6u   /* integer-sum table kernel + general kernel for the remaining tiles */
 
 /* ---- library / context ------------------------------------------------------------------ */
-const char* po_version(void);
+const char* po_version(void);   /* "phyloligo_amd 0.1 (gfx950) src <16 hex digits>": the hash of the sources it was built from */
 int po_abi_version(void);
 const char* po_last_error(void);
 const char* po_status_string(int status);

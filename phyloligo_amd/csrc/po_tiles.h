@@ -203,6 +203,58 @@ __device__ __forceinline__ bool po_tile_mirrors(const po_tile_args& A, uint32_t 
 constexpr int kMirrorLdsStride = 130;                                 // doubles per transposed row (128 + pad)
 constexpr int kMirrorLdsBytes = 32 * kMirrorLdsStride * 8;           // 33 280 B of LDS scratch
 
+// One column group q (record columns j0 + 32 q + 2 tx + {0, 1}) of the register block: v[ia][e].  The direct tile piece is
+// stored, then - when the tile has a mirror - the 32 transposed rows of the group go through LDS and out.  Calling this for
+// q = 0..3 is the whole epilogue; a kernel that produces its values group by group (valu_tile_kernel) calls it as it goes, so
+// that a group's registers are dead before the next group's per-record terms arrive.
+template <typename OUT, int RPT, int NT>
+__device__ __forceinline__ void po_store_block_part(const po_tile_args& A, bool mirrors, uint64_t i0, uint64_t j0, uint32_t tx, uint32_t ty,
+                                                    int q, const double (&v)[RPT][2], double* lds) {
+    OUT* out = static_cast<OUT*>(A.out);
+    const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
+    // ---- the tile itself: two adjacent columns per lane leave as one 16-byte (float64) or 8-byte (float32) store ----
+    const bool vec_out = (A.ld_out & 1) == 0 && ((j0 - A.col_begin) & 1) == 0 &&
+                         (reinterpret_cast<uintptr_t>(A.out) & (2 * sizeof(OUT) - 1)) == 0 && j0 >= A.col_begin;
+    const uint64_t j = j0 + 32 * q + 2 * tx;
+#pragma unroll
+    for (int ia = 0; ia < RPT; ++ia) {
+        const uint64_t i = i0 + ty * RPT + ia;
+        if (i < A.row_begin || i >= n_rows) continue;
+        OUT* row = out + (i - A.row_begin) * A.ld_out;
+        if (vec_out && j + 1 < n_cols) {
+            po_store2(row + (j - A.col_begin), v[ia][0], v[ia][1]);
+        } else {
+            if (j >= A.col_begin && j < n_cols) po_out_store(&row[j - A.col_begin], (OUT)v[ia][0]);
+            if (j + 1 >= A.col_begin && j + 1 < n_cols) po_out_store(&row[j + 1 - A.col_begin], (OUT)v[ia][1]);
+        }
+    }
+    if (!mirrors) return;                                             // uniform over the workgroup
+    // ---- the transposed rows of this group ----
+    OUT* mir = static_cast<OUT*>(A.mirror);
+    const uint32_t t = ty * 16 + tx, lane = t & 63, wave = t >> 6;
+    const bool vec_mir = (A.ld_mirror & 1) == 0 && ((i0 - A.row_begin) & 1) == 0 &&
+                         (reinterpret_cast<uintptr_t>(A.mirror) & (2 * sizeof(OUT) - 1)) == 0 && i0 >= A.row_begin;
+    po_lds_barrier();                                                 // LDS only: the stores above stay in flight
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int ia = 0; ia < RPT; ++ia) lds[(2 * tx + e) * kMirrorLdsStride + ty * RPT + ia] = v[ia][e];
+    po_lds_barrier();
+    for (uint32_t jq = wave; jq < 32; jq += NT / 64) {               // one wave per transposed row
+        const uint64_t jr = j0 + 32 * q + jq;
+        if (jr < A.col_begin || jr >= n_cols) continue;
+        const double2 w = *reinterpret_cast<const double2*>(lds + jq * kMirrorLdsStride + 2 * lane);
+        const uint64_t i = i0 + 2 * lane;
+        OUT* row = mir + (jr - A.col_begin) * A.ld_mirror;
+        if (vec_mir && i + 1 < n_rows) {
+            po_store2(row + (i - A.row_begin), w.x, w.y);
+        } else {
+            if (i >= A.row_begin && i < n_rows) po_out_store(&row[i - A.row_begin], (OUT)w.x);
+            if (i + 1 >= A.row_begin && i + 1 < n_rows) po_out_store(&row[i + 1 - A.row_begin], (OUT)w.y);
+        }
+    }
+}
+
 template <typename OUT, int RPT, int NT>
 __device__ __forceinline__ void po_store_block(const po_tile_args& A, uint32_t ti, uint32_t tj, uint64_t i0, uint64_t j0,
                                                uint32_t tx, uint32_t ty, const double (&v)[RPT][8], double* lds) {

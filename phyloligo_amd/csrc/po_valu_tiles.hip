@@ -116,6 +116,7 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void valu_tile_kernel
     const uint32_t t = threadIdx.x;
     const uint32_t tx = t & 15, ty = t >> 4;
     const uint32_t lane = t & 63, wave = t >> 6;
+    const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);     // for the epilogue (see there)
 
     uint32_t ti, tj;
     po_tile_coords(A, TM, blockIdx.x, ti, tj);
@@ -143,11 +144,11 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void valu_tile_kernel
         constexpr int rows_per_wave = KC * 64 / NT;                     // 2 with 4 waves, 1 with 8
 #pragma unroll
         for (int r = 0; r < rows_per_wave; ++r) {
-            const uint32_t k = wave * rows_per_wave + r;
-            const double* row = A.ft + (uint64_t)(k0 + k) * A.npad + lane * 2;
-            double* dst = stage + buf * kStageDoubles + k * (TM + TN);
-            po_glds16(row + i0, dst);
-            po_glds16(row + j0, dst + TM);
+            const uint32_t k = wave_s * rows_per_wave + r;                // wave-uniform (scalar registers)
+            const double* row = A.ft + (uint64_t)(k0 + k) * A.npad;       // uniform base + a 32-bit lane offset: no 64-bit
+            double* dst = stage + buf * kStageDoubles + k * (TM + TN);    // per-lane pointer has to live across the loop
+            po_glds16(row + i0 + lane * 2, dst);
+            po_glds16(row + j0 + lane * 2, dst + TM);
         }
     };
     gstage(0, 0);
@@ -204,35 +205,56 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void valu_tile_kernel
     if (A.dbl_at != PO_NO_DOUBLING && A.dbl_at >= A.dim) double_sums();
 
     // ---- epilogue -------------------------------------------------------------------------------
+    // The word loop runs at the register limit of four waves per SIMD (128 VGPRs: 64 of accumulators, 24 of fragments, the
+    // lookups in flight).  Anything per-lane that lives ACROSS it gets spilled to scratch memory and reloaded here - round 3
+    // measured that as 3.9 GB of extra HBM writes per 20 GB matrix (104 bytes per lane and tile; profiles/r03_pmc_traffic.txt).
+    // So the lane coordinates are derived again from scratch (wave index kept in a scalar register, lane index from
+    // v_mbcnt: the compiler cannot tie them to the values before the loop), and the per-record terms are fetched one column
+    // pair at a time behind a scheduling barrier instead of all sixteen at once.
+    uint32_t lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const uint32_t t_e = wave_s * 64u + lane_e;
+    const uint32_t tx_e = t_e & 15, ty_e = t_e >> 4;
     // sum f ln f: for JSD the variant computed with this kernel's own table logarithm (errors cancel)
-    const double* st0 = A.rowstat + (METRIC == PO_JSD ? 2 * A.npad : 0);
-    const double* st1 = A.rowstat + A.npad;    // sum f
+    // (tiles are 128-aligned and the per-record arrays padded to npad, a multiple of 128: no index needs clamping; the
+    // bases are wave-uniform pointers and the lane parts 32-bit offsets, pairs of adjacent records one 16-byte load)
+    const double* e_row = A.rowstat + (METRIC == PO_JSD ? 2 * A.npad : 0) + i0;
+    const double* w_row = A.rowstat + A.npad + i0;    // sum f
+    const double* e_col = e_row + (j0 - i0);
+    const double* w_col = w_row + (j0 - i0);
+    const uint32_t ro = ty_e * RPT, co = 2 * tx_e;
+    const bool diag_tile = ti == tj;                   // uniform: metric(x,x) / the squareform diagonal can only be here
     double ei[RPT], wi[RPT];
 #pragma unroll
-    for (int ia = 0; ia < RPT; ++ia) {
-        const uint64_t i = i0 + ty * RPT + ia;
-        ei[ia] = st0[i];
-        wi[ia] = st1[i];
+    for (int ia = 0; ia < RPT; ia += 2) {
+        const double2 e2 = *reinterpret_cast<const double2*>(e_row + ro + ia), w2 = *reinterpret_cast<const double2*>(w_row + ro + ia);
+        ei[ia] = e2.x; ei[ia + 1] = e2.y;
+        wi[ia] = w2.x; wi[ia + 1] = w2.y;
     }
+    const bool mirrors = po_tile_mirrors(A, ti, tj);   // uniform
+    // one column group at a time: its per-record terms, its values, its stores (po_store_block_part) - then its registers are dead
 #pragma unroll
-    for (int ib = 0; ib < 8; ++ib) {
-        const uint64_t j = min(j0 + 32 * (ib >> 1) + 2 * tx + (ib & 1), A.npad - 1);
-        const double ej = st0[j], wj = st1[j];
+    for (int q = 0; q < 4; ++q) {
+        const double2 e2 = *reinterpret_cast<const double2*>(e_col + co + 32 * q), w2 = *reinterpret_cast<const double2*>(w_col + co + 32 * q);
+        double v[RPT][2];
 #pragma unroll
-        for (int ia = 0; ia < RPT; ++ia) {
-            const uint64_t i = i0 + ty * RPT + ia;
-            double v;
-            if (METRIC == PO_JSD) {
-                v = 0.5 * (ei[ia] + ej - acc[ia][ib]) + (0.5 * LN2) * (wi[ia] + wj);
-                v = fmax(v, 0.0);
-            } else {
-                v = acc[ia][ib] / (wi[ia] + wj);                     // 0/0 -> NaN as SciPy gives
+        for (int e = 0; e < 2; ++e) {
+            const double ej = e ? e2.y : e2.x, wj = e ? w2.y : w2.x;
+#pragma unroll
+            for (int ia = 0; ia < RPT; ++ia) {
+                double x;
+                if (METRIC == PO_JSD) {
+                    x = 0.5 * (ei[ia] + ej - acc[ia][2 * q + e]) + (0.5 * LN2) * (wi[ia] + wj);
+                    x = fmax(x, 0.0);
+                } else {
+                    x = acc[ia][2 * q + e] / (wi[ia] + wj);              // 0/0 -> NaN as SciPy gives
+                }
+                if (diag_tile && ro + ia == co + 32 * q + e) x = 0.0;    // metric(x,x) / squareform diagonal
+                v[ia][e] = x;
             }
-            if (i == j) v = 0.0;                                     // metric(x,x) / squareform diagonal
-            acc[ia][ib] = v;
         }
+        po_store_block_part<OUT, RPT, NT>(A, mirrors, i0, j0, tx_e, ty_e, q, v, reinterpret_cast<double*>(smem));
     }
-    po_store_block<OUT, RPT, NT>(A, ti, tj, i0, j0, tx, ty, acc, reinterpret_cast<double*>(smem));
 }
 
 template <int METRIC, int RPT>

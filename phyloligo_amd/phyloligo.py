@@ -381,6 +381,7 @@ def main_distributed(params):
     slab, mirrors = plan.allocate(rank, dev, dtype)
     plan.compute(ctx, counts, totals, params.dist, rank, slab, mirrors)
     torch.cuda.synchronize(dev)
+    t_computed = time.perf_counter()
     if params.large == "memmap":
         # The float32 container needs no second exchange: every rank writes exactly the entries it evaluated - its blocks
         # and their transposes - into their byte ranges of the file (disjoint between ranks by construction of the plan).
@@ -401,7 +402,9 @@ def main_distributed(params):
             for i in np.flatnonzero(empty[a:b]) + a:
                 host[i - a, i - lo] = np.nan
 
+        t_open = time.perf_counter()
         writer = _BlockWriter(fd, n, dev)
+        t_writer = time.perf_counter()
         try:
             for ((r0, r1), (c0, c1), kind, peer), m in zip(plan.work(rank), mirrors):
                 fix = diag_fix if (kind == "diag" and empty is not None and empty[r0:r1].any()) else None
@@ -414,7 +417,10 @@ def main_distributed(params):
             finally:
                 os.close(fd)
         tdist.barrier()
-        _timing("rank %d of %d: distances + container %.3f s" % (rank, world, time.perf_counter() - t_dist0))
+        t_end = time.perf_counter()
+        _timing("rank %d of %d: distances + container %.3f s (allocate + compute %.3f, file reserved + opened %.3f, pinned staging %.3f, "
+                "copy + write %.3f)" % (rank, world, t_end - t_dist0, t_computed - t_dist0, t_open - t_computed, t_writer - t_open,
+                                        t_end - t_writer))
         tdist.destroy_process_group()
         return 0
     # text matrix: rows have to be complete - the transposed blocks go to the ranks whose rows they belong to

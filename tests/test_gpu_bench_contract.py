@@ -27,6 +27,13 @@ def test_bench_json_contract():
     rf = r["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    # the committed counters must have been measured on THIS build of the library
+    assert rf["counters_stale"] is False, rf["counters_stale_what"]
+    assert rf["lib_version"].startswith("phyloligo_amd") and " src " in rf["lib_version"]
+    rag = r["config"]["ragged_assembly"]
+    assert "error" not in rag, rag
+    assert rag["metrics"]["JSD"]["kernel_id"] == 6 and rag["metrics"]["BC"]["kernel_id"] == 7 and rag["metrics"]["Eucl"]["kernel_id"] == 4
+    assert rag["metrics"]["JSD"]["roofline"]["frac"] > 0 and r["value_ragged_assembly"] == rag["metrics"]["JSD"]["pairs_per_s"]
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert r["value"] > 100 * cb["value"]

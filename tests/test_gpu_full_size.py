@@ -126,3 +126,91 @@ def test_full_size_profiles(ctx, pattern, strand, seed):
     recs = [seq[int(off[i]):int(off[i + 1])].tobytes() for i in pick]
     oc, ot = oracle.compute_counts(recs, pattern, strand)
     assert np.array_equal(counts[torch.from_numpy(pick).cuda()].cpu().numpy().astype(np.int64), oc)
+
+
+# ---- a ragged, dirty assembly at full size: the kernels every REAL input gets -------------------------
+@pytest.fixture(scope="module")
+def ragged(ctx):
+    """50 000 contigs, log-normal lengths 1 - 200 kb (0.33 Gb), four base compositions, N runs, lower case, IUPAC codes
+    (phyloligo_amd.synthetic.ragged_assembly) + one record that is nothing but N (an empty profile among 49 999 full ones)."""
+    import torch
+    seq, off = synthetic.ragged_assembly(N, seed=2024)
+    seq = seq.copy()
+    off64 = off.astype(np.int64)
+    seq[off64[12_345]:off64[12_346]] = ord("N")
+    counts, totals = ctx.count_profiles(torch.from_numpy(seq).cuda(), torch.from_numpy(off64).cuda(), "1111", "both")
+    return seq, off64, counts, totals
+
+
+def test_ragged_assembly_profiles(ctx, ragged):
+    """Stage 1 on multi-chunk records (up to 200 kb = ~100 chunks each), separators in most of them: 200 sampled records -
+    the longest, the all-N one and the first / last among them - equal the oracle's counts bit for bit; row sums are the
+    totals; no two blocks of 128 records share a total (every stage-2 tile is a "mixed" tile)."""
+    import torch
+    seq, off, counts, totals = ragged
+    lens = np.diff(off)
+    assert lens.min() >= 1000 and lens.max() == 200_000 and 3.0e8 < off[-1] < 3.6e8
+    assert torch.equal(counts.sum(dim=1, dtype=torch.int64), totals.to(torch.int64))
+    t = totals.cpu().numpy()
+    assert t[12_345] == 0 and int(counts[12_345].abs().sum()) == 0
+    for b in range(0, N, 128):
+        assert np.unique(t[b:b + 128]).size > 1
+    assert 127 < int(counts.max()) <= 16_383                       # two 7-bit digit planes for the exact Gram
+    rng = np.random.default_rng(4)
+    pick = np.unique(np.concatenate([rng.choice(N, size=196, replace=False), [0, N - 1, 12_345, int(np.argmax(lens))]]))
+    recs = [seq[off[i]:off[i + 1]].tobytes() for i in pick]
+    oc, ot = oracle.compute_counts(recs, "1111", "both")
+    assert np.array_equal(counts[torch.from_numpy(pick).cuda()].cpu().numpy().astype(np.int64), oc)
+    assert np.array_equal(t[pick], ot)
+    # the same records on one strand and under a spaced pattern (general path, two histograms): 40 of them
+    sub = pick[::5]
+    for pattern, strand in (("1111", "minus"), ("1101", "both"), ("11011011", "plus")):
+        c2, t2 = ctx.count_profiles(torch.from_numpy(seq).cuda(), torch.from_numpy(off).cuda(), pattern, strand)
+        oc, ot = oracle.compute_counts([seq[off[i]:off[i + 1]].tobytes() for i in sub], pattern, strand)
+        assert np.array_equal(c2[torch.from_numpy(sub).cuda()].cpu().numpy().astype(np.int64), oc), (pattern, strand)
+        assert np.array_equal(t2.cpu().numpy()[sub], ot)
+        del c2, t2
+
+
+@pytest.mark.parametrize("metric,kernel_id,diag,cols", [("JSD", 6, 0.0, None), ("BC", 7, 0.0, None), ("Eucl", 4, 0.0, None),
+                                                        ("SC", 4, 0.0, 8000), ("KT", 8, 1.0, 4000)])
+def test_ragged_assembly_matrix(ctx, ragged, metric, kernel_id, diag, cols):
+    """The whole 50 000 x 50 000 matrix of the ragged assembly through the kernels real data gets - valu_tile_kernel<JSD> /
+    <BC> for every tile (the table / SAD kernels are launched and own nothing), the two-plane exact int8 Gram for Eucl and
+    SC, the pair-dot Gram for KT - against the oracle: three complete rows (rank metrics: three rows x 8 000 / 4 000 columns;
+    the oracle's Kendall is O(D^2) per pair) at rtol 1e-6, exact symmetry, the diagonal, the empty record's row, a row block
+    off the tile grid computed without the symmetry shortcut, and for Eucl the forced float64 Gram on one row block."""
+    import torch
+    seq, off, counts, totals = ragged
+    out = torch.empty((N, N), dtype=torch.float64, device="cuda")
+    _, st = ctx.pairwise(counts, totals, metric, out=out, want_stats=True)
+    assert st["kernel_id"] == kernel_id and st["pairs"] == N * N // 2
+    assert st["rc_folded"] == (metric in ("JSD", "BC", "KT"))
+    assert is_symmetric(out)
+    d = torch.diagonal(out)
+    if metric == "KT":                                   # the empty record is a constant row: tau 0 with everything, itself included
+        assert float(d[12_345]) == 0.0 and bool((torch.cat([d[:12_345], d[12_346:]]) == 1.0).all())
+    elif metric == "SC":                                 # a constant row has no rank correlation: nan, as SciPy gives
+        assert bool(torch.isnan(out[12_345]).all()) and bool((torch.cat([d[:12_345], d[12_346:]]) == 0.0).all())
+    else:
+        assert bool((d == diag).all())
+    sub = ctx.pairwise(counts, totals, metric, row_begin=33_333, row_end=33_600)
+    assert torch.allclose(sub, out[33_333:33_600], rtol=1e-12, atol=1e-15, equal_nan=True)
+    freq = oracle.counts_to_frequencies(counts.cpu().numpy().astype(np.int64), totals.cpu().numpy())
+    longest = int(np.argmax(np.diff(off)))
+    for r in (0, longest, N - 1) + ((12_345,) if cols is None else ()):
+        c0 = 0 if cols is None else (r // 2 if r + 1 < N else N - cols)
+        c1 = N if cols is None else c0 + cols
+        want = oracle.pairwise_block(np.vstack([freq[r:r + 1], freq[c0:c1]]), metric, 0, 1)[0, 1:]
+        if c0 <= r < c1:
+            want[r - c0] = diag if totals[r] > 0 or metric != "KT" else 0.0
+        got = out[r, c0:c1].cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-12, equal_nan=True, err_msg="%s row %d" % (metric, r))
+    if metric in ("JSD", "BC"):
+        # the empty record against a full one: 1/2 ln 2 (phylodist.py:22-24 masks its terms) and 1 (SciPy braycurtis)
+        assert abs(float(out[12_345, 7]) - (0.5 * np.log(2.0) if metric == "JSD" else 1.0)) < 1e-12
+    if metric == "Eucl":
+        f64 = ctx.pairwise(counts, totals, "Eucl", row_begin=20_000, row_end=20_256, table_path=False)
+        assert torch.allclose(f64, out[20_000:20_256], rtol=1e-9, atol=1e-13)
+    del out
+    torch.cuda.empty_cache()

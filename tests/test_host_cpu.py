@@ -205,3 +205,30 @@ def test_scalar_row_loads_are_waited_for_before_use():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_scalar_loads.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ok" in r.stdout
+
+
+def test_no_kernel_spills_registers_to_scratch():
+    """Scratch memory is HBM traffic no algorithmic byte count knows about (3.9 GB of extra writes per
+    matrix came from 27 spilled registers of valu_tile_kernel<JSD>).  Every kernel of the library, compiled with the
+    Makefile's flags, must have no private segment - except the one on the allow list of tools/check_spills.py."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_spills.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "outside the allow list: 0" in r.stdout
+
+
+def test_library_and_committed_counters_belong_to_these_sources():
+    """po_version() carries the hash of the sources the library was built from (tools/source_hash.py); the counter files
+    bench.py quotes (profiles/traffic.json, pmc_busy.json) carry the hash of the library they were measured on.  All three
+    must be the tree's: a kernel edit without `bash tools/profile_round.sh` on the GPU box fails here, before it can put stale
+    counters into a driver-run record (which happened in round 2)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_hash import source_hash
+    tree = source_hash()
+    lib = _lib.load().po_version().decode()
+    assert lib.endswith("src " + tree), "libphyloligo_amd.so is not built from these sources: %s vs tree %s" % (lib, tree)
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    busy = json.load(open(os.path.join(ROOT, "profiles", "pmc_busy.json")))
+    assert traffic["_detail"].get("src_hash") == tree, "profiles/traffic.json was measured on another build: re-run tools/profile_round.sh"
+    assert busy.get("_src_hash") == tree, "profiles/pmc_busy.json was measured on another build: re-run tools/profile_round.sh"

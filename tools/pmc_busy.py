@@ -8,6 +8,15 @@ usage: pmc_busy.py <dir with one sub-directory per pass> [out.json]   (the JSON 
 import collections, glob, json, os, re, sqlite3, sys
 
 
+def lib_identity():
+    """po_version() of the library in this tree - the one the passes just profiled (tools/profile_round.sh runs this script on
+    the same box, same snapshot) - and the source hash inside it (tools/source_hash.py)"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from phyloligo_amd import _lib
+    v = _lib.load().po_version().decode()
+    return v, v.rsplit("src ", 1)[-1] if "src " in v else None
+
+
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     m = re.match(r"([\w:]+(<[^(]*>)?)\(", name)
@@ -44,6 +53,7 @@ for k, v in sorted(vals.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)
     if extra: print("      " + "  ".join("%s=%.4g" % kv for kv in extra.items()))
 
 if len(sys.argv) > 2:
+    summary["_lib_version"], summary["_src_hash"] = lib_identity()
     summary["_source"] = "rocprofv3 --pmc passes over tools/pmc_workload.py (N = 50 000), summarised by tools/pmc_busy.py; busy = fraction of the kernel's GRBM_GUI_ACTIVE time"
     with open(sys.argv[2], "w") as fh:
         json.dump(summary, fh, indent=1)

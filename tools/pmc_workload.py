@@ -10,7 +10,7 @@ n = 50000
 out = torch.empty((n, n), dtype=torch.float64, device="cuda")
 
 
-def profiles(pattern, seed, ragged=False):
+def profiles(pattern, seed, ragged=False):      # (ragged=True: lengths 1.5 - 2.5 kb, the round-3 stand-in; unused now)
     if ragged:
         rng = np.random.default_rng(seed)
         lens = rng.integers(1500, 2500, size=n)
@@ -26,9 +26,13 @@ c, t = profiles("1111", 50001)
 for metric in ("JSD", "Eucl", "BC", "SC", "KT"):
     ctx.pairwise(c, t, metric, out=out)
 ctx.pairwise(c, t, "Eucl", out=out, table_path=False)          # float64 MFMA Gram
-c, t = profiles("1111", 50002, ragged=True)
+# the ragged, dirty assembly of bench.py's config.ragged_assembly and tests/test_gpu_full_size.py (every tile a mixed tile)
+rseq, roff = synthetic.ragged_assembly(n, seed=2024)
+c, t = ctx.count_profiles(torch.from_numpy(rseq).cuda(), torch.from_numpy(roff.astype(np.int64)).cuda(), "1111", "both")
+del rseq
 ctx.pairwise(c, t, "JSD", out=out)                                # general JSD kernel
 ctx.pairwise(c, t, "BC", out=out)                                 # general BC kernel
+ctx.pairwise(c, t, "Eucl", out=out)                               # two digit planes
 c, t = profiles("11011011", 50005)
 ctx.pairwise(c, t, "BC", out=out)                                 # C5: thermometer planes on the matrix cores
 ctx.pairwise(c, t, "BC", out=out, pairdot=False)                  # C5 through the packed-byte SAD kernel
