@@ -128,12 +128,14 @@ class RowBlockPlan:
         return ctx.pairwise_blocks(counts, totals, metric, self.blocks(rank, slab, mirrors), dtype=slab.dtype,
                                    want_stats=want_stats, table_path=table_path)
 
-    def complete_rows(self, rank, slab, mirrors, dist, chunk_bytes=256 << 20):
+    def complete_rows(self, rank, slab, mirrors, dist, chunk_bytes=256 << 20, stage_device=None):
         """Second, optional exchange: send every mirror buffer to the rank whose slab it completes and
         place the received ones.  Point to point (RCCL send/recv over xGMI).  There is at most one message per
         ordered pair of ranks; every message is cut into row chunks of <= chunk_bytes and chunk k of all messages
         is in flight at once, so the receive side needs one bounded staging buffer per peer (not a second copy of
-        its mirrors: at 200 000 contigs on 2 GPUs those are 40 GB next to a 160 GB slab)."""
+        its mirrors: at 200 000 contigs on 2 GPUs those are 40 GB next to a 160 GB slab).
+        stage_device: where the receive staging lives (default: with the slab).  The rehearsal on one GPU moves host tensors
+        over gloo - mirrors given as host tensors, stage_device="cpu" - and still places them into the slab on the device."""
         import torch
         lo, hi = self.rows(rank)
         if dist is None or self.world == 1:
@@ -154,7 +156,7 @@ class RowBlockPlan:
                 if src == rank:
                     sends.append((mirrors[idx], peer, per, nch))
                 if peer == rank:                                 # rows [c0,c1) of my slab, columns [r0,r1)
-                    stage = torch.empty((min(per, c1 - c0), r1 - r0), dtype=slab.dtype, device=slab.device)
+                    stage = torch.empty((min(per, c1 - c0), r1 - r0), dtype=slab.dtype, device=stage_device or slab.device)
                     recvs.append((stage, src, per, nch, c0 - lo, c1 - lo, r0, r1))
         for k in range(steps):
             ops, placed = [], []

@@ -383,8 +383,13 @@ def main_distributed(params):
     torch.cuda.synchronize(dev)
     t_computed = time.perf_counter()
     if params.large == "memmap":
-        # The float32 container needs no second exchange: every rank writes exactly the entries it evaluated - its blocks
-        # and their transposes - into their byte ranges of the file (disjoint between ranks by construction of the plan).
+        # The row-completing exchange runs first (point to point over xGMI: cheap next to any file system), so that every
+        # rank holds ITS ROWS of the matrix whole and writes one contiguous byte range of the file in large pieces.  Measured
+        # on the gpurun box (tools/ubench/container_write_modes.cpp, page cache of overlay/ext4, 3.6 GB): buffered writes
+        # take the inode lock, so ranks that each pwrite their 60 kB pieces of every row reach 4.7 GB/s between two of them and
+        # 2.5 GB/s between eight (the lock changes hands at every call; round 3 did exactly that, 0.82 s for this file),
+        # a shared mapping written with memcpy 0.6 - 2.7 GB/s, while contiguous row slabs in large pieces reach 11 GB/s from
+        # two and 15.6 GB/s from eight processes.
         if params.out_freq_file and rank == 0:
             print("Writing frequency matrix")
             api.write_mat_text(params.out_freq_file, ctx.frequencies(counts, totals).cpu().numpy())
@@ -394,23 +399,27 @@ def main_distributed(params):
                 _reserve_file(fd0, n * n * 4)
             finally:
                 os.close(fd0)
-        tdist.barrier()
+        empty = (totals.cpu().numpy() == 0) if params.dist == "BC" else None
+
+        def diag_fix(host, a, b):                               # rows [a, b) of the matrix, whole
+            _bc_memmap_diagonal(host, a, b, np.flatnonzero(empty[a:b]) + a)
+
+        fix = diag_fix if (empty is not None and empty[lo:hi].any()) else None
+        if rehearsal:                                           # gloo moves host tensors; the slab stays on the device
+            mirrors_h = [None if m is None else m.cpu() for m in mirrors]
+            del mirrors
+            plan.complete_rows(rank, slab, mirrors_h, tdist, stage_device="cpu")
+            del mirrors_h
+        else:
+            plan.complete_rows(rank, slab, mirrors, tdist)
+            del mirrors
+        torch.cuda.synchronize(dev)
+        t_exchanged = time.perf_counter()
+        tdist.barrier()                                         # the file exists and has its size
         fd = os.open(params.out_file, os.O_RDWR)
-        empty = totals.cpu().numpy() == 0 if params.dist == "BC" else None
-
-        def diag_fix(host, a, b):                               # rows [a, b) x columns [lo, hi) of a diagonal block
-            for i in np.flatnonzero(empty[a:b]) + a:
-                host[i - a, i - lo] = np.nan
-
-        t_open = time.perf_counter()
         writer = _BlockWriter(fd, n, dev)
-        t_writer = time.perf_counter()
         try:
-            for ((r0, r1), (c0, c1), kind, peer), m in zip(plan.work(rank), mirrors):
-                fix = diag_fix if (kind == "diag" and empty is not None and empty[r0:r1].any()) else None
-                writer.put(slab[r0 - lo:r1 - lo, c0:c1], r0, c0, fix=fix)
-                if m is not None:
-                    writer.put(m, c0, r0)
+            writer.put(slab, lo, 0, fix=fix)                    # device -> pinned host chunks -> parallel pwrite, overlapped
         finally:
             try:
                 writer.close()
@@ -418,9 +427,8 @@ def main_distributed(params):
                 os.close(fd)
         tdist.barrier()
         t_end = time.perf_counter()
-        _timing("rank %d of %d: distances + container %.3f s (allocate + compute %.3f, file reserved + opened %.3f, pinned staging %.3f, "
-                "copy + write %.3f)" % (rank, world, t_end - t_dist0, t_computed - t_dist0, t_open - t_computed, t_writer - t_open,
-                                        t_end - t_writer))
+        _timing("rank %d of %d: distances + container %.3f s (allocate + compute %.3f, row-completing exchange %.3f, copy + write %.3f)"
+                % (rank, world, t_end - t_dist0, t_computed - t_dist0, t_exchanged - t_computed, t_end - t_exchanged))
         tdist.destroy_process_group()
         return 0
     # text matrix: rows have to be complete - the transposed blocks go to the ranks whose rows they belong to

@@ -48,6 +48,9 @@ def main():
             times = [float(x) for x in re.findall(r"distances \+ container ([0-9.]+) s", r.stderr)]
             res[name] = (max(times), wall, os.path.getsize(out), sha(out))
             print("%-14s distances + container %.3f s (slowest rank), process wall %.2f s, %d bytes" % (name, max(times), wall, res[name][2]), flush=True)
+            for ln in r.stderr.splitlines():
+                if "phyloligo_amd timing" in ln:
+                    print("    " + ln.strip())
             if name != "single":
                 assert res[name][3] == res["single"][3], "container bytes differ"
                 os.remove(out)
