@@ -22,16 +22,24 @@ which = sys.argv[1] if len(sys.argv) > 1 else "all"
 configs = (("1111", "both"), ("1111", "plus"), ("11011011", "both"), ("1101", "both"), ("111111", "both"), ("111111", "minus"),
            ("1111", "minus"), ("1101", "minus"), ("110100111", "both"), ("1011", "both"), ("10011", "both"), ("11101", "both"),
            ("11111", "both"))
-if which not in ("all", "ragged"):
+if which not in ("all", "ragged", "ragged_dirty"):
     configs = tuple(c for c in configs if "%s_%s" % c == which)
-if which == "ragged":
+if which in ("ragged", "ragged_dirty"):
     configs = ()
 for pattern, strand in configs:
     t, c = best(dseq, doff, pattern, strand)
     nbytes = seq.size + c.numel() * 4 + 50000 * 8
     print("C2 %-9s %-5s %7.1f us  %5.2f TB/s algorithmic (%.0f MB)" % (pattern, strand, t * 1e6, nbytes / t / 1e12, nbytes / 1e6), flush=True)
-if which not in ("all", "ragged"):
+if which not in ("all", "ragged", "ragged_dirty"):
     sys.exit(0)
+if which in ("all", "ragged_dirty"):      # the assembly of bench.py's config.ragged_assembly: + N runs, lower case, IUPAC codes, 4 compositions
+    s3, o3 = synthetic.ragged_assembly(50000, seed=2024)
+    t, c = best(torch.from_numpy(s3).cuda(), torch.from_numpy(o3.astype(np.int64)).cuda(), "1111", "both")
+    nbytes = int(o3[-1]) + c.numel() * 4 + 50000 * 8
+    print("ragged_dirty %.2f Gb 1111 both %7.1f us  %5.2f TB/s algorithmic" % (s3.size / 1e9, t * 1e6, nbytes / t / 1e12), flush=True)
+    del s3
+    if which == "ragged_dirty":
+        sys.exit(0)
 rng = np.random.default_rng(2024)
 n = 50000
 lens = np.clip(np.exp(rng.normal(np.log(4000), 1.0, size=n)), 1000, 200000).astype(np.int64)
