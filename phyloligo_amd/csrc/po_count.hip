@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
                                                          const uint64_t* __restrict__ ends, uint32_t n,
                                                          const uint32_t* __restrict__ blocksum,
                                                          const uint32_t* __restrict__ total,
-                                                         uint32_t* __restrict__ chunk_start) {
+                                                         uint32_t* __restrict__ chunk_start,
+                                                         uint32_t* __restrict__ rec_of_chunk) {
     __shared__ uint32_t part[256];
     const uint32_t t = threadIdx.x;
     const uint32_t base = blockIdx.x * 1024 + t * 4;
@@ -210,9 +211,28 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
         __syncthreads();
     }
     uint32_t run = blocksum[blockIdx.x] + part[t] - s;
+    // ... and the inverse map chunk -> record, so that a counting wave finds its record with ONE load instead of a 16-step
+    // dependent search through chunk_start (round 4: the search was ~2 us of a wave's ~12 us on multi-chunk assemblies).
+    // Records of up to 32 chunks are written by their own lane; longer ones (> 64 kb) by the whole wave, one after the other.
+    uint32_t first[4];
+    bool big = false;
     for (uint32_t e = 0; e < 4; ++e) {
         if (base + e < n) chunk_start[base + e] = run;
+        first[e] = run;
+        if (c[e] <= 32u) { for (uint32_t q = 0; q < c[e]; ++q) rec_of_chunk[run + q] = base + e; }
+        else big = true;
         run += c[e];
+    }
+    unsigned long long todo = __ballot(big);
+    const uint32_t lane = t & 63;
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t cnt = (uint32_t)__shfl((int)c[e], src, 64), at = (uint32_t)__shfl((int)first[e], src, 64);
+            const uint32_t rec = (uint32_t)__shfl((int)(base + e), src, 64);
+            if (cnt > 32u) for (uint32_t q = lane; q < cnt; q += 64) rec_of_chunk[at + q] = rec;
+        }
     }
     if (blockIdx.x == 0 && t == 0) chunk_start[n] = *total;
 }
@@ -227,6 +247,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
                                                          const uint64_t* __restrict__ begins,
                                                          const uint64_t* __restrict__ ends,
                                                          const uint32_t* __restrict__ chunk_start,
+                                                         const uint32_t* __restrict__ rec_of_chunk,
                                                          const uint32_t* __restrict__ max_chunks,
                                                          CountParams P, uint32_t waves_per_block,
                                                          uint32_t* __restrict__ counts,
@@ -255,17 +276,8 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
         if (multi) { __syncthreads(); __syncthreads(); }
         return;
     }
-    // record of chunk b = last record with chunk_start <= b.  When every record so far is a single chunk (any
-    // assembly of contigs up to 2 kb) that is record b itself: two loads instead of a 16-step dependent search.
-    uint32_t lo = 0, hi = P.n_seqs;
-    if (b < P.n_seqs && chunk_start[b] <= b && b < chunk_start[b + 1]) {
-        lo = b;
-    } else {
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (chunk_start[mid] <= b) lo = mid; else hi = mid;
-        }
-    }
+    // record of chunk b: the inverse map the scan wrote next to chunk_start (one scalar load)
+    const uint32_t lo = rec_of_chunk[b];
     const uint32_t rec = lo;
     const uint32_t chunk = b - chunk_start[rec];
     const uint32_t rec_chunks = chunk_start[rec + 1] - chunk_start[rec];
@@ -712,13 +724,14 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     if (max_chunks >= (1ull << 31)) { po_set_error("input too large for one launch"); return PO_EUNSUPPORTED; }
 
     const uint32_t nb = (uint32_t)((n_seqs + 1023) / 1024);
-    int rc = po_buf_reserve(ctx, &ctx->ws_aux, (n_seqs + 1 + 2 * (uint64_t)nb + 2) * sizeof(uint32_t));
+    int rc = po_buf_reserve(ctx, &ctx->ws_aux, (n_seqs + 1 + 2 * (uint64_t)nb + 2 + max_chunks) * sizeof(uint32_t));
     if (rc) return rc;
     uint32_t* chunk_start = static_cast<uint32_t*>(ctx->ws_aux.p);
     uint32_t* blocksum = chunk_start + n_seqs + 1;
     uint32_t* total = blocksum + nb;
     uint32_t* blockmax = total + 1;
     uint32_t* d_max_chunks = blockmax + nb;
+    uint32_t* rec_of_chunk = d_max_chunks + 1;                     // [max_chunks]: chunk -> record, written by scan_apply_kernel
 
     // rows of single-chunk records are written whole by their wave; only multi-chunk records (rare:
     // longer than 2 kb) accumulate with atomics and need zeros first.  Zero everything: 1 memset.
@@ -729,7 +742,7 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     PO_CHECK_LAUNCH("scan_block_sums_kernel");
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, blocksum, nb, total, blockmax, d_max_chunks);
     PO_CHECK_LAUNCH("scan_sums_kernel");
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_begins, d_ends, (uint32_t)n_seqs, blocksum, total, chunk_start);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_begins, d_ends, (uint32_t)n_seqs, blocksum, total, chunk_start, rec_of_chunk);
     PO_CHECK_LAUNCH("scan_apply_kernel");
 
     CountParams P;
@@ -776,7 +789,7 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     const int mode = (strand == PO_STRAND_PLUS || P.sym) ? 0 : (strand == PO_STRAND_MINUS ? 1 : 2);
     auto launch = [&](auto k) -> int {
         PO_SHMEM(ctx, k, shmem);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(64 * wpb), shmem, ctx->stream, d_seq, d_begins, d_ends, chunk_start, d_max_chunks, P, wpb, d_counts, tot);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(64 * wpb), shmem, ctx->stream, d_seq, d_begins, d_ends, chunk_start, rec_of_chunk, d_max_chunks, P, wpb, d_counts, tot);
         return PO_OK;
     };
     int lrc = PO_OK;
