@@ -29,6 +29,21 @@ __device__ __host__ inline uint32_t rc_word(uint32_t w, uint32_t k) {
     return r;
 }
 
+// Could record `row` belong to a 128-record block with one common total?  Only if it shares its non-zero total with the
+// records 1, 3, 7, 15, 31, 63 and 127 places on (taken cyclically inside its block; a block of one record is its own mate).
+// In a block that does have one total every record says yes.  In a ragged assembly seven coincidences at once do not happen
+// even when a tenth of the records share a total (contigs cut off at a minimum length: 0.1^8 per record), so that "nobody
+// said yes" tells the host - in the one flag word it reads anyway - that the equal-total kernels would own no tile and need
+// neither their operands nor their launches.
+__device__ __forceinline__ bool fold_some_equal(const unsigned long long* __restrict__ totals, uint64_t row, uint64_t n,
+                                                unsigned long long tot) {
+    const uint64_t first = row & ~(uint64_t)127, size = min((uint64_t)128, n - first);
+    bool all = tot > 0;
+#pragma unroll
+    for (uint32_t step = 1; step < 128; step = 2 * step + 1) all = all && totals[first + (row - first + step) % size] == tot;
+    return all;
+}
+
 // A workgroup stages `rpb` whole records in LDS with coalesced loads (records are contiguous in memory), then
 // every lane takes folded columns: the representative word and its reverse complement are compared (both
 // reads hit LDS, so the scattered partner costs nothing in HBM) and the representative is written out.
@@ -86,6 +101,7 @@ __global__ __launch_bounds__(256) void rc_fold_kernel(const T* __restrict__ in, 
             uint32_t bits = 0;
             if (!(common && sum_s[r] == tot && max_s[r] <= 127u)) bits |= PO_FOLD_NOT_ALL_TABLE;
             if (!(common && max_s[r] <= 255u)) bits |= PO_FOLD_NOT_ALL_SAD;
+            if (fold_some_equal(totals, row, n, tot)) bits |= PO_FOLD_SOME_EQUAL;
             if (bits) atomicOr(asym, bits);
         }
     }
@@ -133,6 +149,7 @@ __global__ __launch_bounds__(256) void rc_fold_long_kernel(const T* __restrict__
             uint32_t bits = 0;
             if (!(common && sum == tot && mx <= 127u)) bits |= PO_FOLD_NOT_ALL_TABLE;
             if (!(common && mx <= 255u)) bits |= PO_FOLD_NOT_ALL_SAD;
+            if (fold_some_equal(totals, row, n, tot)) bits |= PO_FOLD_SOME_EQUAL;
             if (bits) atomicOr(asym, bits);
         }
     }

@@ -158,6 +158,9 @@ uint32_t po_fold_selfs(uint32_t dim);   // self-paired words of a 4^k word space
 #define PO_FOLD_ASYM 1u            // flag bits of the fold pass: some record is not reverse-complement symmetric
 #define PO_FOLD_NOT_ALL_TABLE 2u   // some 128-record block does not qualify for the JSD integer-sum table kernel
 #define PO_FOLD_NOT_ALL_SAD 4u     // some 128-record block does not qualify for the packed SAD kernel (BC)
+#define PO_FOLD_SOME_EQUAL 8u      // some record shares its (non-zero) total with seven other records of its 128-record block: a block
+                                   // with one common total MAY exist.  Clear = certainly none does: a ragged assembly, where the
+                                   // equal-total kernels (JSD table, BC SAD / thermometer) would be launched to own no tile at all
 int po_rc_fold(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq, const uint64_t* d_totals, uint64_t n,
                uint32_t dim, uint32_t gran, bool* folded, uint32_t* dim_f, uint32_t* dbl_at, uint32_t* flags_out);
 // cls (may be NULL): per 128-record block, the common word total if the equal-total table path owns

@@ -32,7 +32,8 @@ def test_bench_json_contract():
     assert rf["lib_version"].startswith("phyloligo_amd") and " src " in rf["lib_version"]
     rag = r["config"]["ragged_assembly"]
     assert "error" not in rag, rag
-    assert rag["metrics"]["JSD"]["kernel_id"] == 6 and rag["metrics"]["BC"]["kernel_id"] == 7 and rag["metrics"]["Eucl"]["kernel_id"] == 4
+    # ragged totals: the general kernels alone (ids 1 / 2; the equal-total kernels would own no tile and are not launched)
+    assert rag["metrics"]["JSD"]["kernel_id"] == 1 and rag["metrics"]["BC"]["kernel_id"] == 2 and rag["metrics"]["Eucl"]["kernel_id"] == 4
     assert rag["metrics"]["JSD"]["roofline"]["frac"] > 0 and r["value_ragged_assembly"] == rag["metrics"]["JSD"]["pairs_per_s"]
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb

@@ -206,3 +206,36 @@ def test_jsd_table_kernel_widths_not_multiple_of_four(ctx, dim):
     want = po.pairwise_block(po.counts_to_frequencies(counts.astype(np.int64), totals), "JSD")
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-12)
     assert got[3, 7] < 1e-13 and np.array_equal(got, got.T)
+
+
+@pytest.mark.parametrize("metric,eq_id,gen_id", [("JSD", 6, 1), ("BC", 7, 2)])
+def test_equal_total_kernels_skipped_only_when_no_block_can_qualify(ctx, metric, eq_id, gen_id):
+    """The fold pass tells the host whether ANY 128-record block could have one common total (every record of such a block
+    shares its total with two block mates); only a certain "no" leaves the table / SAD kernels out.  Ragged totals -> the
+    general kernel alone; one uniform block hidden in a ragged assembly, a single-record last block, a uniform assembly ->
+    the equal-total kernel takes part; results equal the oracle either way, and chance coincidences of two totals change nothing."""
+    from oracle import phyloligo_oracle as po
+    rng = np.random.default_rng(5)
+
+    def run(contigs, want_id):
+        want_id = (want_id,) if isinstance(want_id, int) else want_id
+        seq, offsets = pack(contigs)
+        counts, totals = ctx.count_profiles(seq, offsets, "1111", "both")
+        got, st = ctx.pairwise(counts, totals, metric, want_stats=True)
+        assert st["kernel_id"] in want_id, (st["kernel_id"], want_id)
+        oc, ot = po.compute_counts(contigs, "1111", "both")
+        np.testing.assert_allclose(got, po.pairwise_block(po.counts_to_frequencies(oc, ot), metric), rtol=RTOL, atol=ATOL, equal_nan=True)
+
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    lens = rng.permutation(np.arange(400, 400 + 300))                       # 300 records, no two lengths alike
+    ragged = [alpha[rng.integers(0, 4, size=int(n))].tobytes() for n in lens]
+    run(ragged, gen_id)
+    pairs = list(ragged)
+    for i in range(0, 300, 10):                                             # a tenth of the records share one total (a length cut-off):
+        pairs[i] = alpha[rng.integers(0, 4, size=400)].tobytes()            # coincidences, but no block of 128 with one total
+    run(pairs, gen_id)
+    hidden = list(ragged)
+    hidden[128:256] = [alpha[rng.integers(0, 4, size=700)].tobytes() for _ in range(128)]     # one uniform block inside
+    run(hidden, eq_id)
+    run(ragged[:257], eq_id)                                                 # the last block is a single record: trivially uniform
+    run([alpha[rng.integers(0, 4, size=600)].tobytes() for _ in range(200)], eq_id if metric == "JSD" else 9)   # 9: thermometer planes
