@@ -37,11 +37,18 @@ __device__ __host__ inline uint32_t rc_word(uint32_t w, uint32_t k) {
 // neither their operands nor their launches.
 __device__ __forceinline__ bool fold_some_equal(const unsigned long long* __restrict__ totals, uint64_t row, uint64_t n,
                                                 unsigned long long tot) {
-    const uint64_t first = row & ~(uint64_t)127, size = min((uint64_t)128, n - first);
-    bool all = tot > 0;
+    const uint64_t first = row & ~(uint64_t)127;
+    const uint32_t size = (uint32_t)min((uint64_t)128, n - first), at = (uint32_t)(row - first);   // 32-bit: a 64-bit % is ~150 instructions
+    unsigned long long mate[7];                          // seven independent loads in flight, not a chain of short-circuited ones
 #pragma unroll
-    for (uint32_t step = 1; step < 128; step = 2 * step + 1) all = all && totals[first + (row - first + step) % size] == tot;
-    return all;
+    for (uint32_t q = 0; q < 7; ++q) {
+        const uint32_t x = at + ((2u << q) - 1u);        // < 256
+        mate[q] = totals[first + (size == 128u ? (x & 127u) : x % size)];
+    }
+    uint32_t same = tot > 0 ? 1u : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < 7; ++q) same &= (mate[q] == tot) ? 1u : 0u;
+    return same != 0u;
 }
 
 // A workgroup stages `rpb` whole records in LDS with coalesced loads (records are contiguous in memory), then
@@ -102,7 +109,9 @@ __global__ __launch_bounds__(256) void rc_fold_kernel(const T* __restrict__ in, 
             if (!(common && sum_s[r] == tot && max_s[r] <= 127u)) bits |= PO_FOLD_NOT_ALL_TABLE;
             if (!(common && max_s[r] <= 255u)) bits |= PO_FOLD_NOT_ALL_SAD;
             if (fold_some_equal(totals, row, n, tot)) bits |= PO_FOLD_SOME_EQUAL;
-            if (bits) atomicOr(asym, bits);
+            // (read first: on a uniform assembly EVERY record reports PO_FOLD_SOME_EQUAL, and 50 000 atomics on one address
+            // serialise - 65 -> 157 us for this kernel; a stale 0 only costs a redundant atomic)
+            if (bits && (*reinterpret_cast<const volatile uint32_t*>(asym) & bits) != bits) atomicOr(asym, bits);
         }
     }
 }
@@ -150,7 +159,9 @@ __global__ __launch_bounds__(256) void rc_fold_long_kernel(const T* __restrict__
             if (!(common && sum == tot && mx <= 127u)) bits |= PO_FOLD_NOT_ALL_TABLE;
             if (!(common && mx <= 255u)) bits |= PO_FOLD_NOT_ALL_SAD;
             if (fold_some_equal(totals, row, n, tot)) bits |= PO_FOLD_SOME_EQUAL;
-            if (bits) atomicOr(asym, bits);
+            // (read first: on a uniform assembly EVERY record reports PO_FOLD_SOME_EQUAL, and 50 000 atomics on one address
+            // serialise - 65 -> 157 us for this kernel; a stale 0 only costs a redundant atomic)
+            if (bits && (*reinterpret_cast<const volatile uint32_t*>(asym) & bits) != bits) atomicOr(asym, bits);
         }
     }
 }
