@@ -108,6 +108,8 @@ def test_frequency_input_recovers_the_integer_profiles(ctx):
     counts[7] = 0                                          # empty record
     counts[8, 3:] = 0; counts[8, :3] = (2, 4, 6)           # smallest count 2: n/2 = 6 -> an equivalent reduced pair (c/2, n/2)
     counts[9, :] = 3                                       # constant record; smallest count 3 divides the total
+    for i in range(129, 256):                              # records 128 .. 255: permutations of one profile = ONE block with a common
+        counts[i] = rng.permutation(counts[128])           # total, so that the equal-total kernels take part (ids 6 / 7 below)
     totals = counts.sum(1).astype(np.uint64)
     freq = ctx.frequencies(counts, totals)
     ids = {"Eucl": 4, "JSD": 6, "BC": 7, "SC": 4, "KT": 8}
