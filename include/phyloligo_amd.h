@@ -123,7 +123,7 @@ int po_ctx_set_stream(po_ctx* ctx, void* hip_stream);   /* hipStream_t of the ca
 int po_ctx_synchronize(po_ctx* ctx);
 int po_ctx_device_name(po_ctx* ctx, char* buf, size_t len);
 /* Frees every device workspace the context has grown (operand matrices, the materialised Kendall / Bray-Curtis
- * operand of up to 24 GB, staging of the host-pointer forms); the next call allocates again.  The reference's
+ * operand of up to 96 GB, staging of the host-pointer forms); the next call allocates again.  The reference's
  * workers hold nothing between calls (joblib processes, bin/phyloligo.py:386-390): this is the way back to that. */
 int po_ctx_trim(po_ctx* ctx);
 

@@ -212,7 +212,10 @@ struct po_pairdot_plan {
 bool po_kt_pairdot_supported(uint32_t dim);
 size_t po_kt_pairdot_rank_bytes(uint64_t n, uint32_t dim);
 size_t po_kt_pairdot_operand_bytes(uint64_t n, uint32_t dim, uint32_t words, uint32_t n_selfs, bool folded, int fmt_fp4);
-#define PO_PAIRDOT_MAX_OPERAND (24ull << 30)   // the materialised operand lives in the context's workspace until it is destroyed
+// The materialised operand lives in the context's workspace until a call for another metric, po_ctx_trim or po_ctx_destroy.
+// 96 GB of the 288 GB of HBM3E (round 4; 24 GB before): Kendall at k = 6 is 1.05 MB of FP4 pair signs per record, so the matrix-core
+// path now reaches ~90 000 records there (3.4 x the panel kernel, tools/exp/kt_big.py); a failed allocation falls back to the panel kernel
+#define PO_PAIRDOT_MAX_OPERAND (96ull << 30)
 int po_launch_kt_pairdot_prep(po_ctx* ctx, const uint32_t* d_lessrank, uint64_t n, uint32_t dim, uint64_t npad,
                               const uint32_t* fold_src, uint32_t n_selfs, uint32_t n_pairs, int fmt_fp4,
                               po_pairdot_plan* plan);

@@ -131,3 +131,29 @@ def test_kt_pairdot_large_word_spaces(ctx, pattern, strand, n):
         assert np.array_equal(fast, ctx.pairwise(counts, totals, "KT", table_path=False))
     assert np.array_equal(fast, fast.T) and fast[5, 9] == 1.0 and np.all(np.diag(fast) == 1.0)
     np.testing.assert_array_equal(ctx.pairwise(counts, totals, "KT", row_begin=7, row_end=101), fast[7:101])
+
+
+def test_kendall_k6_operand_beyond_24_gb(ctx):
+    """Round 4: the materialised pair-sign operand may take up to 96 GB of the 288 GB of HBM (24 GB before).  Kendall at k = 6 is
+    1.05 MB of FP4 signs per record: 25 000 records = 26 GB, which round 3 sent to the panel kernel.  The matrix-core Gram and the
+    panel kernel (pairdot=False) agree bit for bit on row blocks at both ends of the matrix; one row against the SciPy-pinned oracle."""
+    import torch
+    from oracle import phyloligo_oracle as po
+    from phyloligo_amd import synthetic
+    n = 25_000
+    seq, off = synthetic.contig_bytes(n, 2000, seed=606)
+    counts, totals = ctx.count_profiles(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), "111111", "both")
+    a, st = ctx.pairwise(counts, totals, "KT", row_begin=0, row_end=256, want_stats=True)
+    assert st["kernel_id"] == 8 and st["rc_folded"]
+    b, st_p = ctx.pairwise(counts, totals, "KT", row_begin=0, row_end=256, pairdot=False, want_stats=True)
+    assert st_p["kernel_id"] == 8                               # the panel kernel reports the same family id
+    assert torch.equal(a, b)
+    a2 = ctx.pairwise(counts, totals, "KT", row_begin=n - 130, row_end=n)
+    b2 = ctx.pairwise(counts, totals, "KT", row_begin=n - 130, row_end=n, pairdot=False)
+    assert torch.equal(a2, b2)
+    freq = po.counts_to_frequencies(counts[:1].cpu().numpy().astype(np.int64), totals[:1].cpu().numpy())
+    cols = np.array([1, 2, 777, n - 1])
+    fc = po.counts_to_frequencies(counts[torch.from_numpy(cols).cuda()].cpu().numpy().astype(np.int64), totals[torch.from_numpy(cols).cuda()].cpu().numpy())
+    want = np.array([po.KT(freq[0], fc[i]) for i in range(len(cols))])
+    np.testing.assert_allclose(a[0, torch.from_numpy(cols).cuda()].cpu().numpy(), want, rtol=1e-6, atol=1e-12)
+    ctx.trim()                                                  # 26 GB of operand go back

@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 import phyloligo_amd as pa
 from phyloligo_amd import synthetic
 ctx = pa.Context(0)
-for pattern, n in (("11111", 20000), ("111111", 10000)):
+for pattern, n in (("11111", 20000), ("111111", 10000), ("111111", 25000), ("111111", 50000)):      # 26 GB / 52 GB of FP4 pair signs: beyond round 3's 24 GB bound
     out = torch.empty((n, n), dtype=torch.float64, device="cuda")
     seq, off = synthetic.contig_bytes(n, 2000, seed=50001)
     c, t = ctx.count_profiles(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), pattern, "both")
