@@ -218,10 +218,10 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void valu_tile_kernel
     // sum f ln f: for JSD the variant computed with this kernel's own table logarithm (errors cancel)
     // (tiles are 128-aligned and the per-record arrays padded to npad, a multiple of 128: no index needs clamping; the
     // bases are wave-uniform pointers and the lane parts 32-bit offsets, pairs of adjacent records one 16-byte load)
-    const double* e_row = A.rowstat + (METRIC == PO_JSD ? 2 * A.npad : 0) + i0;
-    const double* w_row = A.rowstat + A.npad + i0;    // sum f
-    const double* e_col = e_row + (j0 - i0);
-    const double* w_col = w_row + (j0 - i0);
+    const double* e_all = A.rowstat + (METRIC == PO_JSD ? 2 * A.npad : 0);
+    const double* w_all = A.rowstat + A.npad;          // sum f
+    const double* e_row = e_all + i0, *w_row = w_all + i0;
+    const double* e_col = e_all + j0, *w_col = w_all + j0;
     const uint32_t ro = ty_e * RPT, co = 2 * tx_e;
     const bool diag_tile = ti == tj;                   // uniform: metric(x,x) / the squareform diagonal can only be here
     double ei[RPT], wi[RPT];

@@ -417,7 +417,8 @@ def main_distributed(params):
         t_exchanged = time.perf_counter()
         tdist.barrier()                                         # the file exists and has its size
         fd = os.open(params.out_file, os.O_RDWR)
-        writer = _BlockWriter(fd, n, dev)
+        # (two pinned chunks of at most 256 MB; pinning costs ~0.07 s per GB, a small job does not pay for more than its slab)
+        writer = _BlockWriter(fd, n, dev, chunk_bytes=min(256 << 20, max(1 << 20, (hi - lo) * n * 4)))
         try:
             writer.put(slab, lo, 0, fix=fix)                    # device -> pinned host chunks -> parallel pwrite, overlapped
         finally:
