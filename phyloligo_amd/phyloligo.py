@@ -18,6 +18,7 @@ from . import api
 from ._lib import METRICS, STRANDS
 
 _ctx = None
+LAST_STAGE2 = None       # PoStats of the first stage-2 call of the last compute_distances() (what --json-stats reports)
 
 
 def _timing(text):
@@ -257,11 +258,19 @@ def compute_distances(mthdrun, large, frequencies, freq_name, out_file, dist, th
                                not np.array_equal(ctx.frequencies(counts, totals), np.asarray(frequencies))):
         counts = totals = None
 
+    global LAST_STAGE2
+    LAST_STAGE2 = None
+
     def rows(lo, hi, dtype, symmetric, out=None):
+        global LAST_STAGE2
         if counts is not None:
-            return ctx.pairwise(counts, totals, dist, lo, hi, dtype=dtype, symmetric=symmetric, out=out)
-        return ctx.pairwise_freq(np.asarray(frequencies, dtype=np.float64), dist, lo, hi, dtype=dtype,
-                                 symmetric=symmetric, out=out)
+            res, st = ctx.pairwise(counts, totals, dist, lo, hi, dtype=dtype, symmetric=symmetric, out=out, want_stats=True)
+        else:
+            res, st = ctx.pairwise_freq(np.asarray(frequencies, dtype=np.float64), dist, lo, hi, dtype=dtype,
+                                        symmetric=symmetric, out=out, want_stats=True)
+        if LAST_STAGE2 is None:
+            LAST_STAGE2 = dict(st, rows=[int(lo), int(hi)])
+        return res
 
     if large == "memmap":
         fix = None
@@ -314,6 +323,9 @@ def get_cmd(argv=None):
     parser.add_argument("-w", "--workdir", action="store", dest="workdir", default=".", help="working directory")
     parser.add_argument("-p", "--pattern", action="store", dest="pattern", default="1111",
                         help="spaced-word pattern string, only containing 1s and 0s, i.e. '100101001', default='1111'")
+    parser.add_argument("--json-stats", action="store", dest="json_stats", default=None,
+                        help="not in the reference (SURVEY section 5): write sizes, phase times and the stage-2 kernel of this run "
+                             "to this file as JSON; the five progress lines on stdout stay as they are")
     parser.add_argument("--gpus", action="store", dest="gpus", type=int, default=1,
                         help="not in the reference: GPUs of this node to use, one process each (python -m phyloligo_amd starts "
                              "the ranks itself; the analogue of the reference fanning out to -c joblib workers) [default:%(default)d]")
@@ -334,6 +346,7 @@ def main_distributed(params):
     import torch
     import torch.distributed as tdist
     from .dist import RowBlockPlan
+    t_start = time.perf_counter()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     rehearsal = os.environ.get("PO_CLI_REHEARSAL") == "1"
     local = 0 if rehearsal else int(os.environ.get("LOCAL_RANK", "0"))
@@ -430,6 +443,8 @@ def main_distributed(params):
         t_end = time.perf_counter()
         _timing("rank %d of %d: distances + container %.3f s (allocate + compute %.3f, row-completing exchange %.3f, copy + write %.3f)"
                 % (rank, world, t_end - t_dist0, t_computed - t_dist0, t_exchanged - t_computed, t_end - t_exchanged))
+        if params.json_stats and rank == 0:
+            _write_json_stats(params, _Shape(n, int(counts.shape[1])), t_dist0 - t_start, t_end - t_dist0, 0.0, t_end - t_start, gpus=world)
         tdist.destroy_process_group()
         return 0
     # text matrix: rows have to be complete - the transposed blocks go to the ranks whose rows they belong to
@@ -458,6 +473,10 @@ def main_distributed(params):
             for a, rows in row_chunks():
                 api.write_mat_text(params.out_file, rows, append=(r > 0 or a > 0))
         tdist.barrier()
+    if params.json_stats and rank == 0:
+        t_end = time.perf_counter()
+        _write_json_stats(params, _Shape(n, int(counts.shape[1])), t_dist0 - t_start, t_computed - t_dist0, t_end - t_computed,
+                          t_end - t_start, gpus=world)
     tdist.destroy_process_group()
     return 0
 
@@ -468,6 +487,7 @@ def main(argv=None):
         params.pattern = str("1") * params.pattern
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         return main_distributed(params)
+    t_start = time.perf_counter()
     print("Using pattern {}".format(params.pattern))
     if not os.path.isdir(params.workdir):
         os.makedirs(params.workdir)
@@ -475,11 +495,13 @@ def main(argv=None):
     frequencies, freq_name = compute_frequencies(params.mthdrun, params.large, params.genome, params.pattern,
                                                  params.strand, params.distchunksize, params.threads_max,
                                                  params.workdir)
+    t_freq = time.perf_counter()
     print("Computing Pairwise distances")
     t_dist0 = time.perf_counter()
     res = compute_distances(params.mthdrun, params.large, frequencies, freq_name, params.out_file, params.dist,
                             params.threads_max, params.freqchunksize, params.workdir)
-    _timing("single process: distances%s %.3f s" % (" + container" if params.large == "memmap" else "", time.perf_counter() - t_dist0))
+    t_dist = time.perf_counter()
+    _timing("single process: distances%s %.3f s" % (" + container" if params.large == "memmap" else "", t_dist - t_dist0))
     if params.out_freq_file:
         print("Writing frequency matrix")
         api.write_mat_text(params.out_freq_file, np.asarray(frequencies))
@@ -487,7 +509,32 @@ def main(argv=None):
         print("Writing distance matrix")
         if res is not None:                  # None: unknown --method, nothing was computed (:552 only prints)
             api.write_mat_text(params.out_file, res)
+    if params.json_stats and frequencies is not None:
+        _write_json_stats(params, frequencies, t_freq - t_start, t_dist - t_dist0, time.perf_counter() - t_dist, time.perf_counter() - t_start)
     return 0
+
+
+class _Shape:
+    """stands in for the frequency matrix where only its shape is wanted (--json-stats of a multi-rank run)"""
+
+    def __init__(self, n, dim):
+        self.shape = (n, dim)
+
+
+def _write_json_stats(params, frequencies, freq_s, dist_s, write_s, total_s, gpus=1):
+    """--json-stats ("keep the same five lines for CLI fidelity; add --json-stats")"""
+    import json
+    from . import _lib
+    n, dim = (int(x) for x in frequencies.shape)
+    stats = {"library": _lib.load().po_version().decode(), "device": _context().device_name, "gpus": gpus,
+             "assembly": os.path.abspath(params.genome), "contigs": n, "words": dim, "pattern": str(params.pattern),
+             "strand": params.strand, "metric": params.dist, "large": params.large, "pairs": n * (n - 1) // 2,
+             "seconds": {"frequencies": freq_s, "distances" + ("_and_container" if params.large == "memmap" else ""): dist_s,
+                         "writing": write_s, "total": total_s},
+             "stage2_first_call": LAST_STAGE2}
+    with open(params.json_stats, "w") as fh:
+        json.dump(stats, fh, indent=1)
+        fh.write("\n")
 
 
 if __name__ == "__main__":

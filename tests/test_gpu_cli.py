@@ -298,3 +298,21 @@ def test_cli_process_runs_without_torch(fasta, tmp_path):
                          capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert open(raw_ref, "rb").read() == open(raw_got, "rb").read()
+
+
+def test_json_stats(fasta, tmp_path, capsys):
+    """--json-stats: sizes, phase times, library and device, the stage-2 kernel of the run - next to the
+    five progress lines, which stay exactly the reference's."""
+    import json
+    from phyloligo_amd import phyloligo as P
+    path, g = fasta
+    out, js = tmp_path / "o.mat", tmp_path / "stats.json"
+    assert P.main(["-i", path, "-k", "4", "-d", "JSD", "--method", "joblib", "-o", str(out), "--json-stats", str(js)]) == 0
+    assert capsys.readouterr().out.splitlines() == ["Using pattern 1111", "Computing frequencies", "Computing Pairwise distances",
+                                                    "Writing distance matrix"]
+    st = json.loads(js.read_text())
+    assert st["contigs"] == 48 and st["words"] == 256 and st["pairs"] == 48 * 47 // 2 and st["metric"] == "JSD" and st["gpus"] == 1
+    assert st["library"].startswith("phyloligo_amd") and len(st["device"]) > 0
+    assert set(st["seconds"]) == {"frequencies", "distances", "writing", "total"} and st["seconds"]["total"] > 0
+    assert st["stage2_first_call"]["kernel_id"] in (1, 6) and st["stage2_first_call"]["rows"] == [0, 48]
+    np.testing.assert_allclose(np.loadtxt(out, delimiter="\t"), g["JSD_1111_both"], rtol=1e-6, atol=1e-12)
