@@ -120,8 +120,9 @@ def _reserve_file(fd, size):
     os.ftruncate(fd, size)
 
 
-def _pwrite_rows(fd, host, row0, col0, n, threads=8):
-    """host[R, C] float32 (unit inner stride) -> rows row0.., columns col0.. of the n x n float32 container behind fd
+def _pwrite_rows(fd, host, row0, col0, n, threads=8, base=0):
+    """host[R, C] float32 (unit inner stride) -> rows row0.., columns col0.. of the n x n float32 matrix that starts at byte
+    `base` of the file behind fd (0: the raw container; the data offset of the "distances" dataset: the HDF5 container)
     (po_pwrite_rows: parallel pwrite in C, no Python per row)."""
     import ctypes
     from . import _lib
@@ -130,7 +131,7 @@ def _pwrite_rows(fd, host, row0, col0, n, threads=8):
         return
     assert host.dtype == np.float32 and host.strides[1] == 4 and host.strides[0] >= cols * 4
     _lib.check(_lib.load().po_pwrite_rows(fd, ctypes.c_void_p(host.ctypes.data), rows, cols * 4, host.strides[0],
-                                          (row0 * n + col0) * 4, n * 4, threads))
+                                          base + (row0 * n + col0) * 4, n * 4, threads))
 
 
 def _bc_memmap_diagonal(buf, lo, hi, empty):
@@ -143,16 +144,19 @@ def _bc_memmap_diagonal(buf, lo, hi, empty):
             buf[i - lo, i] = np.nan
 
 
-def _write_raw_f32(out_file, n, rows, writers=8, fix=None):
+def _write_raw_f32(out_file, n, rows, writers=8, fix=None, base=None):
     """The container of compute_distances_memmap (phyloligo.py:394-427): headerless row-major float32[n, n] (:413), the
     file phyloligo_comparemat.py:16-24 and phyloselect.py:606-614 read back.  Row blocks come off the device into
     one of two reusable host buffers and go to the file through po_pwrite_rows (parallel pwrite) on a background thread
     while the next block is computed and copied: no second ndarray, no page faults on a file mapping (numpy.memmap
     assignment measured ~3 GB/s).  fix(buf, lo, hi): host-side touch-up of a finished row block before it is written."""
     import concurrent.futures as cf
-    fd = os.open(out_file, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
+    # base is None: a new raw container.  base = byte offset: the matrix goes into an EXISTING file from there on (the HDF5
+    # container: created and sized by libhdf5, phyloligo_amd/hdf5.py)
+    fd = os.open(out_file, os.O_RDWR | (0 if base is not None else os.O_CREAT | os.O_TRUNC), 0o666)
     try:
-        _reserve_file(fd, n * n * 4)
+        if base is None:
+            _reserve_file(fd, n * n * 4)
         if n == 0:
             return
         step = min(n, _row_chunk(n, 4, budget=512 << 20))
@@ -168,7 +172,7 @@ def _write_raw_f32(out_file, n, rows, writers=8, fix=None):
                 rows(lo, hi, "float32", lo == 0 and hi == n, out=buf)
                 if fix is not None:
                     fix(buf, lo, hi)
-                pending[which] = pool.submit(_pwrite_rows, fd, buf, lo, 0, n, writers)
+                pending[which] = pool.submit(_pwrite_rows, fd, buf, lo, 0, n, writers, base or 0)
             for f in pending:
                 if f is not None:
                     f.result()
@@ -181,10 +185,10 @@ class _BlockWriter:
     _write_raw_f32): two pinned host buffers; the device-to-host copy of chunk k + 1 runs on a side stream while
     po_pwrite_rows (parallel pwrite) puts chunk k into the file from a background thread."""
 
-    def __init__(self, fd, n, device, chunk_bytes=256 << 20, writers=8):
+    def __init__(self, fd, n, device, chunk_bytes=256 << 20, writers=8, base=0):
         import concurrent.futures as cf
         import torch
-        self.torch, self.fd, self.n, self.writers = torch, fd, n, writers
+        self.torch, self.fd, self.n, self.writers, self.base = torch, fd, n, writers, base
         self.chunk = chunk_bytes
         self.stage = [torch.empty(chunk_bytes // 4, dtype=torch.float32, pin_memory=True) for _ in range(2)]
         self.pending = [None, None]
@@ -213,7 +217,7 @@ class _BlockWriter:
             host = view.numpy()
             if fix is not None:
                 fix(host, row0 + a, row0 + b)
-            self.pending[which] = self.pool.submit(_pwrite_rows, self.fd, host, row0 + a, col0, self.n, self.writers)
+            self.pending[which] = self.pool.submit(_pwrite_rows, self.fd, host, row0 + a, col0, self.n, self.writers, self.base)
 
     def close(self):
         try:
@@ -235,16 +239,20 @@ def compute_distances(mthdrun, large, frequencies, freq_name, out_file, dist, th
                       workdir="."):
     """phyloligo.py:536-553.  `--large None`: returns the float64[N,N] matrix (main writes it).
     `--large memmap`: writes the headerless float32 row-major matrix to out_file as
-    compute_distances_memmap does (:394-427, container dtype :413) and returns None."""
+    compute_distances_memmap does (:394-427, container dtype :413) and returns None.
+    `--large h5py`: writes the HDF5 file of compute_distances_h5py / join_distance_results (:456-534): one float32 dataset
+    "distances" of shape (N, N), and returns None."""
     if mthdrun not in ("joblib", "scoop", "hip"):
         print("Error, method {} is not implemented for pairwise distances computation".format(mthdrun), file=sys.stderr)
         return None
     if dist not in METRICS:                                                  # :383-385
         print("Error, unknown metric methodfor joblib: {}".format(dist), file=sys.stderr)
         sys.exit(1)
-    if large == "h5py":
-        print("Error, --large h5py needs the h5py container, which this build does not provide", file=sys.stderr)
-        sys.exit(1)
+    if large == "h5py" and mthdrun != "scoop":
+        from . import hdf5
+        if not hdf5.available():
+            print("Error, --large h5py needs libhdf5 (>= 1.10), which was not found on this system", file=sys.stderr)
+            sys.exit(1)
     ctx = _context()
     counts = getattr(frequencies, "counts", None)
     totals = getattr(frequencies, "totals", None)
@@ -272,13 +280,18 @@ def compute_distances(mthdrun, large, frequencies, freq_name, out_file, dist, th
             LAST_STAGE2 = dict(st, rows=[int(lo), int(hi)])
         return res
 
-    if large == "memmap":
+    if large in ("memmap", "h5py"):
         fix = None
-        if dist == "BC":
+        if dist == "BC":                     # BC_loc and BC_h5py both go through phylodist.BC (SciPy cdist): see _bc_memmap_diagonal
             empty = np.flatnonzero(~np.asarray(frequencies).any(axis=1))
             if empty.size:
                 fix = lambda buf, lo, hi: _bc_memmap_diagonal(buf, lo, hi, empty)      # noqa: E731
-        _write_raw_f32(out_file, n, rows, fix=fix)
+        base = None
+        if large == "h5py":
+            # join_distance_results (:456-478): ONE dataset "distances", (N, N), float32.  libhdf5 creates and sizes the file; the
+            # matrix then goes into the dataset's contiguous data range exactly as it goes into the raw container
+            base = hdf5.create_f32_dataset(out_file, "distances", n, n)
+        _write_raw_f32(out_file, n, rows, fix=fix, base=base)
         return None
     if n * n * 8 <= _SINGLE_CALL_BYTES:
         return rows(0, n, "float64", True)
@@ -350,10 +363,16 @@ def main_distributed(params):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     rehearsal = os.environ.get("PO_CLI_REHEARSAL") == "1"
     local = 0 if rehearsal else int(os.environ.get("LOCAL_RANK", "0"))
-    if params.mthdrun not in ("joblib", "hip") or params.large == "h5py":
+    if params.mthdrun not in ("joblib", "hip"):
         if rank == 0:
-            print("Error, the multi-GPU run supports --method joblib|hip with --large None|memmap", file=sys.stderr)
+            print("Error, the multi-GPU run supports --method joblib|hip", file=sys.stderr)
         sys.exit(1)
+    if params.large == "h5py":
+        from . import hdf5
+        if not hdf5.available():
+            if rank == 0:
+                print("Error, --large h5py needs libhdf5 (>= 1.10), which was not found on this system", file=sys.stderr)
+            sys.exit(1)
     if params.strand not in STRANDS or params.dist not in METRICS:
         sys.exit(1)
     torch.cuda.set_device(local)
@@ -390,12 +409,12 @@ def main_distributed(params):
         counts, totals = plan.all_gather_profiles(my_counts, my_totals, tdist)
     say("Computing Pairwise distances")
     t_dist0 = time.perf_counter()
-    dtype = torch.float32 if params.large == "memmap" else torch.float64
+    dtype = torch.float32 if params.large in ("memmap", "h5py") else torch.float64
     slab, mirrors = plan.allocate(rank, dev, dtype)
     plan.compute(ctx, counts, totals, params.dist, rank, slab, mirrors)
     torch.cuda.synchronize(dev)
     t_computed = time.perf_counter()
-    if params.large == "memmap":
+    if params.large in ("memmap", "h5py"):
         # The row-completing exchange runs first (point to point over xGMI: cheap next to any file system), so that every
         # rank holds ITS ROWS of the matrix whole and writes one contiguous byte range of the file in large pieces.  Measured
         # on the gpurun box (tools/ubench/container_write_modes.cpp, page cache of overlay/ext4, 3.6 GB): buffered writes
@@ -406,12 +425,17 @@ def main_distributed(params):
         if params.out_freq_file and rank == 0:
             print("Writing frequency matrix")
             api.write_mat_text(params.out_freq_file, ctx.frequencies(counts, totals).cpu().numpy())
+        base = [0]
         if rank == 0:
-            fd0 = os.open(params.out_file, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
-            try:
-                _reserve_file(fd0, n * n * 4)
-            finally:
-                os.close(fd0)
+            if params.large == "h5py":                          # libhdf5 creates and sizes the file; the ranks fill the dataset's data range
+                base[0] = hdf5.create_f32_dataset(params.out_file, "distances", n, n)
+            else:
+                fd0 = os.open(params.out_file, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
+                try:
+                    _reserve_file(fd0, n * n * 4)
+                finally:
+                    os.close(fd0)
+        tdist.broadcast_object_list(base, src=0)                # where the matrix starts in the file
         empty = (totals.cpu().numpy() == 0) if params.dist == "BC" else None
 
         def diag_fix(host, a, b):                               # rows [a, b) of the matrix, whole
@@ -431,7 +455,7 @@ def main_distributed(params):
         tdist.barrier()                                         # the file exists and has its size
         fd = os.open(params.out_file, os.O_RDWR)
         # (two pinned chunks of at most 256 MB; pinning costs ~0.07 s per GB, a small job does not pay for more than its slab)
-        writer = _BlockWriter(fd, n, dev, chunk_bytes=min(256 << 20, max(1 << 20, (hi - lo) * n * 4)))
+        writer = _BlockWriter(fd, n, dev, chunk_bytes=min(256 << 20, max(1 << 20, (hi - lo) * n * 4)), base=int(base[0]))
         try:
             writer.put(slab, lo, 0, fix=fix)                    # device -> pinned host chunks -> parallel pwrite, overlapped
         finally:
@@ -501,7 +525,7 @@ def main(argv=None):
     res = compute_distances(params.mthdrun, params.large, frequencies, freq_name, params.out_file, params.dist,
                             params.threads_max, params.freqchunksize, params.workdir)
     t_dist = time.perf_counter()
-    _timing("single process: distances%s %.3f s" % (" + container" if params.large == "memmap" else "", t_dist - t_dist0))
+    _timing("single process: distances%s %.3f s" % (" + container" if params.large in ("memmap", "h5py") else "", t_dist - t_dist0))
     if params.out_freq_file:
         print("Writing frequency matrix")
         api.write_mat_text(params.out_freq_file, np.asarray(frequencies))
@@ -529,7 +553,7 @@ def _write_json_stats(params, frequencies, freq_s, dist_s, write_s, total_s, gpu
     stats = {"library": _lib.load().po_version().decode(), "device": _context().device_name, "gpus": gpus,
              "assembly": os.path.abspath(params.genome), "contigs": n, "words": dim, "pattern": str(params.pattern),
              "strand": params.strand, "metric": params.dist, "large": params.large, "pairs": n * (n - 1) // 2,
-             "seconds": {"frequencies": freq_s, "distances" + ("_and_container" if params.large == "memmap" else ""): dist_s,
+             "seconds": {"frequencies": freq_s, "distances" + ("_and_container" if params.large in ("memmap", "h5py") else ""): dist_s,
                          "writing": write_s, "total": total_s},
              "stage2_first_call": LAST_STAGE2}
     with open(params.json_stats, "w") as fh:

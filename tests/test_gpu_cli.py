@@ -316,3 +316,51 @@ def test_json_stats(fasta, tmp_path, capsys):
     assert set(st["seconds"]) == {"frequencies", "distances", "writing", "total"} and st["seconds"]["total"] > 0
     assert st["stage2_first_call"]["kernel_id"] in (1, 6) and st["stage2_first_call"]["rows"] == [0, 48]
     np.testing.assert_allclose(np.loadtxt(out, delimiter="\t"), g["JSD_1111_both"], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("metric", ["Eucl", "JSD", "BC"])
+def test_h5py_container_equals_the_memmap_container(fasta, tmp_path, metric, capsys):
+    """--large h5py (bin/phyloligo.py:456-534): one HDF5 file with the float32 dataset "distances" (N, N), as
+    join_distance_results writes it and phyloselect.py:615-619 reads it.  Same mathematics as the memmap variant
+    (euclidean_distances_h5py / JSD_h5py / BC_h5py mirror the *_loc functions), so libhdf5 must read back exactly the float32
+    values of the raw container - which is pinned by the reference's own bytes (test_memmap_container_vs_...)."""
+    from phyloligo_amd import hdf5, phyloligo as P
+    if not hdf5.available():
+        pytest.skip("no libhdf5 >= 1.10 on this system")
+    path, g = fasta
+    raw, h5 = tmp_path / "out.f32", tmp_path / "out.h5"
+    args = ["-i", path, "-p", "1111", "-d", metric, "--method", "joblib"]
+    assert P.main(args + ["--large", "memmap", "-o", str(raw)]) == 0
+    assert P.main(args + ["--large", "h5py", "-o", str(h5)]) == 0
+    printed = capsys.readouterr().out.splitlines()
+    assert printed[-3:] == ["Using pattern 1111", "Computing frequencies", "Computing Pairwise distances"]    # no text matrix (:1064)
+    got = hdf5.read_f32_dataset(str(h5), "distances")
+    want = np.fromfile(raw, dtype=np.float32).reshape(48, 48)
+    assert got.shape == (48, 48) and np.array_equal(got, want, equal_nan=True)
+
+
+def test_h5py_container_from_two_ranks(tmp_path):
+    """the same HDF5 container written by two ranks (rehearsal on one GPU): rank 0 lets libhdf5 create the file, every rank fills
+    its rows of the dataset's data range; libhdf5 reads back the single-process values"""
+    import subprocess
+    import sys
+    from phyloligo_amd import hdf5, phyloligo as P
+    if not hdf5.available():
+        pytest.skip("no libhdf5 >= 1.10 on this system")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(3)
+    fa = tmp_path / "asm.fa"
+    with open(fa, "wb") as fh:
+        for i in range(301):
+            s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(rng.integers(300, 3000)))].tobytes()
+            fh.write(b">c%d\n" % i + s + b"\n")
+    one, two = tmp_path / "one.h5", tmp_path / "two.h5"
+    args = ["-i", str(fa), "-k", "4", "-d", "JSD", "--method", "joblib", "--large", "h5py"]
+    assert P.main(args + ["-o", str(one)]) == 0
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PO_CLI_REHEARSAL="1", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-m", "phyloligo_amd", "--gpus", "2"] + args + ["-o", str(two)],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    a, b = hdf5.read_f32_dataset(str(one), "distances"), hdf5.read_f32_dataset(str(two), "distances")
+    assert a.shape == (301, 301) and np.array_equal(a, b)

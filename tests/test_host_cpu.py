@@ -232,3 +232,39 @@ def test_library_and_committed_counters_belong_to_these_sources():
     busy = json.load(open(os.path.join(ROOT, "profiles", "pmc_busy.json")))
     assert traffic["_detail"].get("src_hash") == tree, "profiles/traffic.json was measured on another build: re-run tools/profile_round.sh"
     assert busy.get("_src_hash") == tree, "profiles/pmc_busy.json was measured on another build: re-run tools/profile_round.sh"
+
+
+def test_hdf5_container_without_h5py(tmp_path):
+    """the "distances" dataset of --large h5py (bin/phyloligo.py:471-478: (N, N) float32, one dataset) without
+    h5py - libhdf5 creates and sizes the file, the matrix is written into the dataset's contiguous data range by plain file
+    writes (the path po_pwrite_rows takes), libhdf5 reads it back, and h5dump (the library's own tool) sees what h5py would."""
+    import shutil
+    import subprocess
+    from phyloligo_amd import hdf5
+    if not hdf5.available():
+        pytest.skip("no libhdf5 >= 1.10 on this system")
+    path = tmp_path / "d.h5"
+    n = 37
+    base = hdf5.create_f32_dataset(str(path), "distances", n, n)
+    assert base > 0 and os.path.getsize(path) >= base + n * n * 4
+    m = (np.arange(n * n, dtype=np.float32) / np.float32(7)).reshape(n, n)
+    m[3, 5] = np.nan
+    lib = _lib.load()
+    fd = os.open(path, os.O_RDWR)
+    try:                                                     # rows 0..19 whole, then rows 20.. as two column blocks
+        _lib.check(lib.po_pwrite_rows(fd, m.ctypes.data, 20, n * 4, n * 4, base, n * 4, 3))
+        left, right = np.ascontiguousarray(m[20:, :10]), np.ascontiguousarray(m[20:, 10:])
+        _lib.check(lib.po_pwrite_rows(fd, left.ctypes.data, n - 20, 40, 40, base + 20 * n * 4, n * 4, 2))
+        _lib.check(lib.po_pwrite_rows(fd, right.ctypes.data, n - 20, (n - 10) * 4, (n - 10) * 4, base + (20 * n + 10) * 4, n * 4, 2))
+    finally:
+        os.close(fd)
+    back = hdf5.read_f32_dataset(str(path), "distances")
+    assert back.shape == (n, n) and np.array_equal(back, m, equal_nan=True)
+    h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        head = subprocess.run([h5dump, "-H", str(path)], capture_output=True, text=True, timeout=60).stdout
+        assert 'DATASET "distances"' in head and "H5T_IEEE_F32LE" in head and "( %d, %d )" % (n, n) in head
+    with pytest.raises(OSError):
+        hdf5.read_f32_dataset(str(path), "frequencies")
+    assert hdf5.create_f32_dataset(str(tmp_path / "e.h5"), "distances", 0, 0) == 0
+    assert hdf5.read_f32_dataset(str(tmp_path / "e.h5"), "distances").shape == (0, 0)
