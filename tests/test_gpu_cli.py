@@ -337,6 +337,17 @@ def test_h5py_container_equals_the_memmap_container(fasta, tmp_path, metric, cap
     got = hdf5.read_f32_dataset(str(h5), "distances")
     want = np.fromfile(raw, dtype=np.float32).reshape(48, 48)
     assert got.shape == (48, 48) and np.array_equal(got, want, equal_nan=True)
+    # h5py itself, where an interpreter of this system has it (the image's conda python3.9: h5py 3.3.0): the reference's read
+    import subprocess
+    exe = "/opt/conda/bin/python3.9"
+    if os.path.exists(exe) and subprocess.run([exe, "-c", "import h5py"], capture_output=True).returncode == 0:
+        code = ("import h5py, numpy, sys\n"
+                "with h5py.File(sys.argv[1], 'r') as hf:\n"
+                "    matrix = hf.get('distances'); matrix = matrix[...]\n"          # phyloselect.py:617-619 (.value is h5py < 3)
+                "numpy.save(sys.argv[2], matrix)\n")
+        r = subprocess.run([exe, "-c", code, str(h5), str(tmp_path / "via_h5py.npy")], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert np.array_equal(np.load(tmp_path / "via_h5py.npy"), want, equal_nan=True)
 
 
 def test_h5py_container_from_two_ranks(tmp_path):

@@ -264,6 +264,19 @@ def test_hdf5_container_without_h5py(tmp_path):
     if os.path.exists(h5dump):
         head = subprocess.run([h5dump, "-H", str(path)], capture_output=True, text=True, timeout=60).stdout
         assert 'DATASET "distances"' in head and "H5T_IEEE_F32LE" in head and "( %d, %d )" % (n, n) in head
+    # ... and h5py itself, where some interpreter of this system has it (the image's /opt/conda python3.9 does: 3.3.0), reading
+    # the file the way the reference's readers do (phyloselect.py:615-619: hf.get("distances"), then all of it)
+    for exe in ("/opt/conda/bin/python3.9", "/opt/conda/bin/python"):
+        if os.path.exists(exe) and subprocess.run([exe, "-c", "import h5py"], capture_output=True).returncode == 0:
+            code = ("import h5py, numpy, sys\n"
+                    "with h5py.File(sys.argv[1], 'r') as hf:\n"
+                    "    d = hf.get('distances'); a = d[...]\n"
+                    "    assert d.dtype == numpy.float32 and d.shape == (%d, %d) and d.chunks is None, (d.dtype, d.shape, d.chunks)\n"
+                    "numpy.save(sys.argv[2], a)\n") % (n, n)
+            r = subprocess.run([exe, "-c", code, str(path), str(tmp_path / "via_h5py.npy")], capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stderr[-2000:]
+            assert np.array_equal(np.load(tmp_path / "via_h5py.npy"), m, equal_nan=True)
+            break
     with pytest.raises(OSError):
         hdf5.read_f32_dataset(str(path), "frequencies")
     assert hdf5.create_f32_dataset(str(tmp_path / "e.h5"), "distances", 0, 0) == 0
