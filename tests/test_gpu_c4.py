@@ -123,3 +123,38 @@ def test_c4_rank0_and_rank7_on_one_gpu(c4):
                 assert mask[:plan.bounds[4]].all() and mask[r0:r1].all()
         del slab, mirrors
         torch.cuda.empty_cache()
+
+
+def test_config4_assembly_on_one_gpu_float32():
+    """The north star's own size on ONE GPU: 200 000 contigs x 2 kb.  The float64 matrix (320 GB) does not fit, the float32 one
+    (160 GB - the container type of --large memmap / h5py) does: JSD through the table kernel with float32 stores, 64-bit
+    indexing over 4e10 entries.  Exact symmetry of far corners, zero diagonal, three complete rows against the oracle (float32
+    rounding of a float64 result: rtol 1e-6), and the forced float64 matrix-core Euclidean on the same 160 GB buffer."""
+    import torch
+    import phyloligo_amd as pa
+    from phyloligo_amd import synthetic
+    from oracle import phyloligo_oracle as po
+    n = 200_000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 175 * (1 << 30):
+        pytest.skip("needs 175 GB of free HBM")
+    seq, off = synthetic.contig_bytes(n, 2000, seed=synthetic.SEEDS["C4"])
+    with pa.Context(0) as ctx:
+        counts, totals = ctx.count_profiles(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), "1111", "both")
+        out = torch.empty((n, n), dtype=torch.float32, device="cuda")
+        freq = None
+        for metric, kw, kid in (("JSD", {}, 6), ("Eucl", {"table_path": False}, 3)):
+            out.fill_(-1.0)
+            _, st = ctx.pairwise(counts, totals, metric, dtype="float32", out=out, want_stats=True, **kw)
+            assert st["kernel_id"] == kid and st["pairs"] == n * n // 2
+            for a0, b0 in ((0, n - 4096), (100_000, 60_000), (n - 4096, 0)):
+                assert torch.equal(out[a0:a0 + 4096, b0:b0 + 4096], out[b0:b0 + 4096, a0:a0 + 4096].T)
+            assert bool((torch.diagonal(out) == 0).all()) and float(out.min()) >= 0.0
+            if freq is None:
+                freq = po.counts_to_frequencies(counts.cpu().numpy().astype(np.int64), totals.cpu().numpy())
+            for r in (0, 123_456, n - 1):
+                want = po.pairwise_block(np.vstack([freq[r:r + 1], freq]), metric, 0, 1)[0, 1:]
+                want[r] = 0.0
+                np.testing.assert_allclose(out[r].cpu().numpy(), want.astype(np.float32), rtol=1e-6, atol=1e-7)
+        del out
+        torch.cuda.empty_cache()
