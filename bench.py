@@ -520,6 +520,43 @@ def main():
             except Exception as exc:             # never let the extras break the headline line
                 others["error"] = repr(exc)
             result["config"]["other_configs"] = others
+        if world == 1 and args.metric == "JSD" and n == 50000 and not args.no_other_configs:
+            # The north star quotes its targets on 200 000 contigs.  Their float64 matrix (320 GB) needs two GPUs (BASELINE config 4,
+            # --gpus N), their float32 matrix (160 GB, the container type of --large memmap / h5py) fits one: JSD and Eucl on both its
+            # paths at that size, float32 stores (tools/c4_single_gpu.py; parity at this size: tests/test_gpu_c4.py).  Not `value`.
+            try:
+                free_b, _ = torch.cuda.mem_get_info(dev)
+                n4 = 200000
+                need = n4 * n4 * 4 + (8 << 30)
+                if free_b < need:
+                    result["config"]["c4_size_one_gpu_float32"] = {"skipped": "needs %.0f GB of free HBM, %.0f GB are free" % (need / 1e9, free_b / 1e9)}
+                else:
+                    seq4, off4 = synthetic.contig_bytes(n4, args.length, seed=synthetic.SEEDS["C4"])
+                    c4, t4 = ctx.count_profiles(torch.from_numpy(seq4).to(dev), torch.from_numpy(off4.astype(np.int64)).to(dev), args.pattern, "both")
+                    del seq4
+                    out4 = torch.empty((n4, n4), dtype=torch.float32, device=dev)
+                    pairs4 = n4 * (n4 - 1) / 2.0
+                    bpp4 = 2 * 4 + 2 * c4.shape[1] * 4 / (n4 - 1)
+                    c4rec = {"workload": "BASELINE config 4's assembly on one GPU: %d contigs x %d bp (seed %d), pattern %s both strands, float32 "
+                                         "matrix (160 GB) resident in HBM" % (n4, args.length, synthetic.SEEDS["C4"], args.pattern), "pairs": pairs4}
+                    for name, metric4, kw in (("JSD", "JSD", {}), ("Eucl_int8", "Eucl", {}), ("Eucl_f64_mfma", "Eucl", {"table_path": False})):
+                        best = None
+                        for _ in range(2):
+                            _, s4 = ctx.pairwise(c4, t4, metric4, dtype="float32", out=out4, want_stats=True, **kw)
+                            if best is None or s4["total_ms"] < best["total_ms"]:
+                                best = s4
+                        rec4 = {"ms": best["total_ms"], "kernel_ms": best["kernel_ms"], "pairs_per_s": pairs4 / (best["total_ms"] * 1e-3),
+                                "kernel_id": best["kernel_id"], "roofline": hbm_roofline(bpp4 * pairs4, best["kernel_ms"], bytes_per_pair=bpp4)}
+                        if kw:
+                            tf4 = 2.0 * c4.shape[1] * pairs4 / (best["kernel_ms"] * 1e-3) / 1e12
+                            rec4["roofline"] = {"bound": "mfma-f64", "achieved": tf4, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                                "frac": tf4 / F64_MFMA_PEAK_TF, "flops_per_pair": 2 * int(c4.shape[1])}
+                        c4rec[name] = rec4
+                    result["config"]["c4_size_one_gpu_float32"] = c4rec
+                    del out4, c4, t4
+                    torch.cuda.empty_cache()
+            except Exception as exc:             # never let the extras break the headline line
+                result["config"]["c4_size_one_gpu_float32"] = {"error": repr(exc)}
         if world == 1 and args.metric == "JSD" and not args.no_ragged:
             # What a REAL assembly gets: the same number of contigs with log-normal lengths 1 - 200 kb,
             # four base compositions, N runs, soft-masked stretches and IUPAC codes (synthetic.ragged_assembly; parity of exactly

@@ -99,6 +99,18 @@ def test_bench_launches_its_own_ranks():
     assert bad.returncode != 0
 
 
+def test_bench_record_of_the_default_run_has_the_north_star_size():
+    """the default run (N = 1, 50 000 contigs) also reports BASELINE config 4's assembly on one GPU with a float32 matrix; read from the
+    committed record of this round (running it here would repeat 160 GB of work the bench test above does not need)"""
+    path = os.path.join(ROOT, "profiles", "r04_bench_jsd_n50000.json")
+    r = json.load(open(path))
+    c4 = r["config"]["c4_size_one_gpu_float32"]
+    assert "error" not in c4 and "skipped" not in c4, c4
+    assert c4["pairs"] == 200000 * 199999 / 2.0
+    assert c4["JSD"]["kernel_id"] == 6 and c4["Eucl_int8"]["kernel_id"] == 4 and c4["Eucl_f64_mfma"]["kernel_id"] == 3
+    assert c4["Eucl_f64_mfma"]["roofline"]["bound"] == "mfma-f64" and c4["Eucl_f64_mfma"]["roofline"]["frac"] > 0.5
+
+
 def test_bench_default_workloads_are_the_baseline_configs():
     """bench.py --gpus 1 = BASELINE config 2, --gpus N > 1 = BASELINE config 4 (read from the source: running 200 000
     contigs needs more than one GPU)."""
