@@ -117,7 +117,8 @@ def _reserve_file(fd, size):
                 return
         except (OSError, AttributeError):
             pass
-    os.ftruncate(fd, size)
+    if os.fstat(fd).st_size < size:          # never shorten: an HDF5 file keeps whatever the library has put behind the data
+        os.ftruncate(fd, size)
 
 
 def _pwrite_rows(fd, host, row0, col0, n, threads=8, base=0):
@@ -155,8 +156,8 @@ def _write_raw_f32(out_file, n, rows, writers=8, fix=None, base=None):
     # container: created and sized by libhdf5, phyloligo_amd/hdf5.py)
     fd = os.open(out_file, os.O_RDWR | (0 if base is not None else os.O_CREAT | os.O_TRUNC), 0o666)
     try:
-        if base is None:
-            _reserve_file(fd, n * n * 4)
+        # blocks allocated up front either way (fallocate keeps what libhdf5 has already written at the head of its file)
+        _reserve_file(fd, (base or 0) + n * n * 4)
         if n == 0:
             return
         step = min(n, _row_chunk(n, 4, budget=512 << 20))
