@@ -218,3 +218,37 @@ def test_ragged_assembly_matrix(ctx, ragged, metric, kernel_id, diag, cols):
         assert torch.allclose(f64, out[20_000:20_256], rtol=1e-9, atol=1e-13)
     del out
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("pattern", ["111111", "11011011"])
+def test_ragged_assembly_large_alphabet(ctx, pattern):
+    """The large word space of BASELINE config 5 (D = 4 096) on RAGGED, dirty data - config 5 itself is equal-length contigs, which
+    take the thermometer / SAD / table kernels; a real assembly at k = 6 takes the general kernels and two digit planes: 8 000
+    contigs of 1 - 60 kb, JSD / BC / Eucl / SC rows against the oracle, symmetry, and three Kendall pairs (the oracle's Kendall is
+    O(D^2) = 8 million comparisons per pair)."""
+    import torch
+    n = 8_000
+    seq, off = synthetic.ragged_assembly(n, seed=77, median=3000, sigma=0.9, lo=1000, hi=60_000)
+    off64 = off.astype(np.int64)
+    counts, totals = ctx.count_profiles(torch.from_numpy(seq).cuda(), torch.from_numpy(off64).cuda(), pattern, "both")
+    pick = [0, 1234, int(np.argmax(np.diff(off64))), n - 1]
+    oc, ot = oracle.compute_counts([seq[off64[i]:off64[i + 1]].tobytes() for i in pick], pattern, "both")
+    assert np.array_equal(counts[torch.tensor(pick).cuda()].cpu().numpy().astype(np.int64), oc)
+    freq = oracle.counts_to_frequencies(counts.cpu().numpy().astype(np.int64), totals.cpu().numpy())
+    out = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    for metric, kid in (("JSD", 1), ("BC", 2), ("Eucl", 4), ("SC", 4)):
+        _, st = ctx.pairwise(counts, totals, metric, out=out, want_stats=True)
+        assert st["kernel_id"] == kid, (metric, st["kernel_id"])
+        assert is_symmetric(out, nan_ok=(metric == "SC"))
+        for r in pick[:3]:
+            want = oracle.pairwise_block(np.vstack([freq[r:r + 1], freq[:2000]]), metric, 0, 1)[0, 1:]
+            if r < 2000:
+                want[r] = 0.0
+            np.testing.assert_allclose(out[r, :2000].cpu().numpy(), want, rtol=1e-6, atol=1e-12, err_msg="%s row %d" % (metric, r))
+    kt, st = ctx.pairwise(counts, totals, "KT", row_begin=0, row_end=2, want_stats=True)
+    assert st["kernel_id"] == 8
+    for j in (1, 4000, n - 1):
+        np.testing.assert_allclose(float(kt[0, j]), oracle.KT(freq[0], freq[j]), rtol=1e-6, atol=1e-12)
+    del out
+    ctx.trim()
+    torch.cuda.empty_cache()
