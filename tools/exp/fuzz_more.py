@@ -23,4 +23,4 @@ for modname, fns in (("tests.test_gpu_fuzz_pairwise", None), ("tests.test_gpu_fu
                 fails += 1
                 print("FAIL %s.%s seed %d: %r" % (modname, name, seed, str(exc)[:300]), flush=True)
         print("%s.%s: seeds %d..%d done" % (modname, name, lo, hi - 1), flush=True)
-print("failures:", fails)
+print("failures:", fails, flush=True)
