@@ -16,9 +16,16 @@ for modname, fns in (("tests.test_gpu_fuzz_pairwise", None), ("tests.test_gpu_fu
         params = list(inspect.signature(fn).parameters)
         if params[:2] != ["ctx", "seed"] or len(params) != 2:
             continue
+        import time
+        t_grp = time.time()
         for seed in range(lo, hi):
+            if (seed - lo) % 25 == 0:
+                print("  %s seed %d (%.0f s so far)" % (name, seed, time.time() - t_grp), flush=True)
             try:
+                t_one = time.time()
                 fn(ctx, seed)
+                if time.time() - t_one > 5:
+                    print("  SLOW %s seed %d: %.1f s" % (name, seed, time.time() - t_one), flush=True)
             except Exception as exc:      # noqa: BLE001
                 fails += 1
                 print("FAIL %s.%s seed %d: %r" % (modname, name, seed, str(exc)[:300]), flush=True)
