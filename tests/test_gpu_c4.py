@@ -125,6 +125,7 @@ def test_c4_rank0_and_rank7_on_one_gpu(c4):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.gpu
 def test_config4_assembly_on_one_gpu_float32():
     """The north star's own size on ONE GPU: 200 000 contigs x 2 kb.  The float64 matrix (320 GB) does not fit, the float32 one
     (160 GB - the container type of --large memmap / h5py) does: JSD through the table kernel with float32 stores, 64-bit
