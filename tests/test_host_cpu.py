@@ -209,8 +209,9 @@ def test_scalar_row_loads_are_waited_for_before_use():
 
 def test_no_kernel_spills_registers_to_scratch():
     """Scratch memory is HBM traffic no algorithmic byte count knows about (3.9 GB of extra writes per
-    matrix came from 27 spilled registers of valu_tile_kernel<JSD>).  Every kernel of the library, compiled with the
-    Makefile's flags, must have no private segment - except the one on the allow list of tools/check_spills.py."""
+    matrix came from 27 spilled registers of valu_tile_kernel<JSD>).  Every kernel inside the BUILT library (the gfx950 code
+    objects of its .hip_fatbin section, metadata read with llvm-readelf) must have no private segment - except the one on the
+    allow list of tools/check_spills.py (`--compile` checks the assembly of a fresh compilation instead)."""
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_spills.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
