@@ -252,3 +252,59 @@ def test_ragged_assembly_large_alphabet(ctx, pattern):
     del out
     ctx.trim()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("pattern,strand,big", [("1111", "both", 2_500_000_000), ("11011011", "plus", 2_500_000_000),
+                                                ("111", "plus", 4_400_000_000)])
+def test_profiles_of_more_than_4_gib_of_sequence(ctx, pattern, strand, big):
+    """Maximum sizes of stage 1: byte offsets beyond 2^32 and ONE record longer than 2^31 (2.5 GB) / 2^32 (4.4 GB) bytes - a
+    chromosome-scale scaffold; the reference has no limit but memory (str slicing, bin/phyloligo.py:601-631).  Layout: 48 dirty,
+    ragged probe records, the long record, 2 000 records of 0.5 - 1.5 MB, the same probe records again (their bytes start
+    beyond 4 GiB).  The probe records equal the oracle at both ends bit for bit; every filler record has its window count
+    ('both' = the record and its reverse complement as one string: 2 L - W + 1, phyloligo.py:141); row sums are the totals; the long
+    record's counts equal a histogram of its words computed by torch in pieces (plus strand, contiguous words)."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * (1 << 30):
+        pytest.skip("needs ~40 GB of free HBM")
+    pseq, poff = synthetic.ragged_assembly(n=48, seed=7, median=20000, sigma=1.0, lo=100, hi=300000)[:2]
+    poff = np.asarray(poff, dtype=np.int64)
+    n_probe = len(poff) - 1
+    rng = np.random.default_rng(11)
+    fill_lens = np.concatenate([[big], rng.integers(500_000, 1_500_000, size=2000)]).astype(np.int64)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    total_fill = int(fill_lens.sum())
+    p = torch.from_numpy(np.asarray(pseq)).cuda()
+    seq = torch.empty(2 * p.numel() + total_fill, dtype=torch.uint8, device="cuda")
+    seq[:p.numel()] = p
+    seq[-p.numel():] = p
+    for a in range(0, total_fill, 1 << 30):
+        b = min(total_fill, a + (1 << 30))
+        seq[p.numel() + a:p.numel() + b] = lut[torch.randint(0, 4, (b - a,), device="cuda", generator=g, dtype=torch.uint8).long()]
+    lens = np.concatenate([np.diff(poff), fill_lens, np.diff(poff)])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    assert off[-1] == seq.numel() and off[-1 - n_probe] > (1 << 32)
+    counts, totals = ctx.count_profiles(seq, torch.from_numpy(off).cuda(), pattern, strand)
+    c = counts.cpu().numpy().view(np.uint32).astype(np.int64)
+    t = totals.cpu().numpy().astype(np.int64)
+    oc, ot = oracle.compute_counts([np.asarray(pseq)[poff[i]:poff[i + 1]].tobytes() for i in range(n_probe)], pattern, strand)
+    assert np.array_equal(c[:n_probe], oc) and np.array_equal(t[:n_probe], ot)
+    assert np.array_equal(c[-n_probe:], oc) and np.array_equal(t[-n_probe:], ot)            # the same bytes beyond 4 GiB
+    span = len(pattern)
+    assert np.array_equal(t[n_probe:-n_probe], (fill_lens * 2 if strand == "both" else fill_lens) - span + 1)
+    assert np.array_equal(c.sum(axis=1), t)
+    if strand == "plus" and set(pattern) == {"1"}:
+        a0, L = int(off[n_probe]), int(fill_lens[0])
+        code = torch.zeros(256, dtype=torch.int64, device="cuda")
+        for i, ch in enumerate(b"CGAT"):                                 # the reference's column order (count2freq :653-658)
+            code[ch] = i
+        hist = torch.zeros(4 ** span, dtype=torch.int64, device="cuda")
+        for s in range(0, L - span + 1, 1 << 28):
+            e = min(L - span + 1, s + (1 << 28))
+            w = torch.zeros(e - s, dtype=torch.int64, device="cuda")
+            for j in range(span):
+                w = w * 4 + code[seq[a0 + s + j:a0 + e + j].long()]
+            hist += torch.bincount(w, minlength=4 ** span)
+        assert torch.equal(hist.cpu(), torch.from_numpy(c[n_probe]))
