@@ -34,6 +34,17 @@ constexpr int kPasses = 1;                         // passes per chunk.  A wave 
 constexpr int kChunkSpan = kSpan * kPasses;
 constexpr int kStage = kTile + 64;                 // staged bytes per chunk (halo >= W-1 = 63 behind the last start at 15 + 2015, multiple of 16 B)
 constexpr uint32_t kMaxLdsBins = 16384;            // 64 KiB histogram; above that count in HBM directly
+// Long records.  The workgroups of a record that crosses workgroups add their histograms into the record's row with global
+// atomics; a record of more than ~1 000 chunks (2 Mb) then has hundreds of workgroups on the same 1 KiB of counters and stage 1
+// fell from 2.1 TB/s of sequence to 0.87 (2 Mb records), 0.34 (20 Mb), 0.16 (>= 200 Mb; profiles/r04_stage1.txt).  So a record of
+// more than kLongChunks chunks adds into SEGMENT rows instead: scratch row s belongs to the record that owns chunk s * kSegChunks,
+// a workgroup of that record whose first chunk lies in segment s adds there (at most 32 workgroups per row; the head of the
+// record, before its first segment boundary, goes to the record's row as before), and seg_rows_sum_kernel adds 16 segments at a
+// time into the record's row - and zeroes them again, so that the scratch is all zeros between calls.
+constexpr uint32_t kSegChunks = 128;
+constexpr uint32_t kLongChunks = 512;
+constexpr uint32_t kSegsPerBlock = 16;
+constexpr uint32_t kWaveFillChunks = 256;          // the scan writes no rec_of_chunk entries for records of more chunks: count_kernel searches
 
 struct CountParams {
     uint32_t window, k, dim, nruns;
@@ -56,6 +67,8 @@ struct CountParams {
     int strand;
     uint32_t n_seqs;
     uint64_t total_bytes;
+    uint32_t* seg_rows;              // [segments][row width] scratch rows of long records (all zero between calls), or null
+    unsigned long long* seg_tot;     // [segments] their word totals
 };
 
 // digit of a base, 4 = not A/C/G/T.  (c>>1)&3 is A0 C1 T2 G3 in either case; 0x72 reorders
@@ -213,7 +226,9 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
     uint32_t run = blocksum[blockIdx.x] + part[t] - s;
     // ... and the inverse map chunk -> record, so that a counting wave finds its record with ONE load instead of a 16-step
     // dependent search through chunk_start (round 4: the search was ~2 us of a wave's ~12 us on multi-chunk assemblies).
-    // Records of up to 32 chunks are written by their own lane; longer ones (> 64 kb) by the whole wave, one after the other.
+    // Records of up to 32 chunks are written by their own lane; longer ones (> 64 kb) by the whole wave, one after the other;
+    // those of more than kWaveFillChunks (0.5 Mb) not at all (one wave wrote for 150 us on a 1 Gb record, and as long on 500
+    // records of 2 Mb that sit in one workgroup of this kernel): count_kernel checks the entry it reads and searches if it is not right.
     uint32_t first[4];
     bool big = false;
     for (uint32_t e = 0; e < 4; ++e) {
@@ -231,10 +246,29 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
         for (uint32_t e = 0; e < 4; ++e) {
             const uint32_t cnt = (uint32_t)__shfl((int)c[e], src, 64), at = (uint32_t)__shfl((int)first[e], src, 64);
             const uint32_t rec = (uint32_t)__shfl((int)(base + e), src, 64);
-            if (cnt > 32u) for (uint32_t q = lane; q < cnt; q += 64) rec_of_chunk[at + q] = rec;
+            if (cnt > 32u && cnt <= kWaveFillChunks) for (uint32_t q = lane; q < cnt; q += 64) rec_of_chunk[at + q] = rec;
         }
     }
     if (blockIdx.x == 0 && t == 0) chunk_start[n] = *total;
+}
+
+// The record of chunk c when some record is longer than kWaveFillChunks chunks and the scan left its entries of rec_of_chunk
+// unwritten (whatever the workspace held): an entry is right iff c lies in that record's chunk range; if not, binary search
+// through chunk_start (the largest record whose first chunk is <= c; ~20 dependent loads, long records only).
+__device__ __forceinline__ uint32_t checked_record_of_chunk(const uint32_t* __restrict__ chunk_start, const uint32_t* __restrict__ rec_of_chunk,
+                                                            uint32_t n_seqs, uint32_t c) {
+    uint32_t lo = rec_of_chunk[c];
+    bool ok = lo < n_seqs;
+    if (ok) ok = chunk_start[lo] <= c && c < chunk_start[lo + 1];
+    if (!ok) {
+        uint32_t hi = n_seqs;                                       // invariant: chunk_start[lo] <= c < chunk_start[hi]
+        lo = 0;
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (chunk_start[mid] <= c) lo = mid; else hi = mid;
+        }
+    }
+    return lo;
 }
 
 // ---- counting: one WAVE per chunk, no workgroup barrier -------------------------------------------
@@ -277,7 +311,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
         return;
     }
     // record of chunk b: the inverse map the scan wrote next to chunk_start (one scalar load)
-    const uint32_t lo = rec_of_chunk[b];
+    const uint32_t lo = *max_chunks > kWaveFillChunks ? checked_record_of_chunk(chunk_start, rec_of_chunk, P.n_seqs, b) : rec_of_chunk[b];
     const uint32_t rec = lo;
     const uint32_t chunk = b - chunk_start[rec];
     const uint32_t rec_chunks = chunk_start[rec + 1] - chunk_start[rec];
@@ -621,14 +655,22 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
     if (lane == 0) {
         if (rec_chunks == 1) totals[rec] = mine_count;
         else if (whole) atomicAdd(&mid_slot[1], mine_count);       // LDS: the group's first wave writes the sum below
-        else if (mine_count) atomicAdd(&totals[rec], (unsigned long long)mine_count);
+        else if (mine_count) {
+            unsigned long long* tot = &totals[rec];
+            if (P.seg_rows != nullptr && rec_chunks > kLongChunks && (b / kSegChunks) * kSegChunks >= chunk_start[rec])
+                tot = &P.seg_tot[b / kSegChunks];                   // long record: its segment's total (seg_rows_sum_kernel)
+            atomicAdd(tot, (unsigned long long)mine_count);
+        }
     }
 
     // ---- flush: the first wave of the record's group, once every wave of the group has counted ------
     if (multi) __syncthreads();
     if (LDS_HIST && wave == lead) {
         __builtin_amdgcn_wave_barrier();
-        uint32_t* row = counts + (uint64_t)rec * (P.marg ? P.out_dim : P.dim);
+        const uint32_t width = P.marg ? P.out_dim : P.dim;
+        uint32_t* row = counts + (uint64_t)rec * width;
+        if (P.seg_rows != nullptr && rec_chunks > kLongChunks && (b / kSegChunks) * kSegChunks >= chunk_start[rec])
+            row = P.seg_rows + (uint64_t)(b / kSegChunks) * width;  // long record (never `whole`: atomics below)
         const uint32_t mid_word = P.sym ? mid_slot[0] : 0xFFFFFFFFu;
         if (whole && rec_chunks > 1 && lane == 0) totals[rec] = mid_slot[1];
         const bool le = fast_done || force_le;
@@ -713,6 +755,63 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
     }
 }
 
+// Long records (see kSegChunks): the segment rows of 16 consecutive segments are added into the rows of the records that own
+// them - one atomic per bin and run of segments with one owner - and zeroed again.  A segment whose first chunk belongs to a
+// record of at most kLongChunks chunks was never written and is not read.
+__global__ __launch_bounds__(256) void seg_rows_sum_kernel(const uint32_t* __restrict__ chunk_start, const uint32_t* __restrict__ rec_of_chunk,
+                                                           const uint32_t* __restrict__ max_chunks, uint32_t n_seqs, uint32_t width,
+                                                           uint32_t* __restrict__ seg_rows, unsigned long long* __restrict__ seg_tot,
+                                                           uint32_t* __restrict__ counts, unsigned long long* __restrict__ totals) {
+    if (*max_chunks <= kLongChunks) return;                        // no long record in this input (uniform)
+    __shared__ uint32_t owner[kSegsPerBlock];
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    const uint32_t nchunks = chunk_start[n_seqs];
+    const uint32_t s0 = blockIdx.x * kSegsPerBlock, t = threadIdx.x;
+    if (t < kSegsPerBlock) {
+        const uint64_t c = (uint64_t)(s0 + t) * kSegChunks;
+        uint32_t o = NONE;
+        if (c < nchunks) {
+            const uint32_t r = checked_record_of_chunk(chunk_start, rec_of_chunk, n_seqs, (uint32_t)c);
+            if (chunk_start[r + 1] - chunk_start[r] > kLongChunks) o = r;
+        }
+        owner[t] = o;
+    }
+    __syncthreads();
+    bool any = false;
+    for (uint32_t s = 0; s < kSegsPerBlock; ++s) any = any || owner[s] != NONE;
+    if (!any) return;                                              // uniform
+    if (t == 0) {
+        uint32_t cur = NONE;
+        unsigned long long acc = 0;
+        for (uint32_t s = 0; s < kSegsPerBlock; ++s) {
+            const uint32_t o = owner[s];
+            if (o != cur) {
+                if (cur != NONE && acc) atomicAdd(&totals[cur], acc);
+                cur = o; acc = 0;
+            }
+            if (o != NONE) { acc += seg_tot[s0 + s]; seg_tot[s0 + s] = 0; }
+        }
+        if (cur != NONE && acc) atomicAdd(&totals[cur], acc);
+    }
+    for (uint32_t d = t; d < width; d += 256) {
+        uint32_t v[kSegsPerBlock];
+#pragma unroll
+        for (uint32_t s = 0; s < kSegsPerBlock; ++s)               // independent loads first
+            v[s] = owner[s] != NONE ? seg_rows[(uint64_t)(s0 + s) * width + d] : 0u;
+        uint32_t cur = NONE, acc = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < kSegsPerBlock; ++s) {
+            const uint32_t o = owner[s];
+            if (o != cur) {
+                if (cur != NONE && acc) atomicAdd(&counts[(uint64_t)cur * width + d], acc);
+                cur = o; acc = 0;
+            }
+            if (v[s]) { acc += v[s]; seg_rows[(uint64_t)(s0 + s) * width + d] = 0u; }
+        }
+        if (cur != NONE && acc) atomicAdd(&counts[(uint64_t)cur * width + d], acc);
+    }
+}
+
 }  // namespace
 
 int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins, const uint64_t* d_ends, uint64_t n_seqs,
@@ -765,6 +864,17 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     P.total_bytes = total_bytes;
 
     const bool lds_hist = pat.dim <= kMaxLdsBins;
+    // segment rows of long records: only when the input can hold one; zeroed when (re)allocated, kept zero by seg_rows_sum_kernel
+    const uint64_t n_segs = max_chunks / kSegChunks + 1;
+    const bool seg = lds_hist && max_chunks > kLongChunks;
+    if (seg) {
+        const size_t cap_before = ctx->ws_seg.cap;
+        rc = po_buf_reserve(ctx, &ctx->ws_seg, n_segs * ((uint64_t)pat.dim * sizeof(uint32_t) + sizeof(uint64_t)));
+        if (rc) return rc;
+        if (ctx->ws_seg.cap != cap_before) PO_HIP(hipMemsetAsync(ctx->ws_seg.p, 0, ctx->ws_seg.cap, ctx->stream));
+        P.seg_tot = static_cast<unsigned long long*>(ctx->ws_seg.p);                 // 8-byte entries first
+        P.seg_rows = reinterpret_cast<uint32_t*>(P.seg_tot + n_segs);
+    }
     // -s both, spaced pattern of at most 4 positions, not its own mirror image (1101, 1011): count contiguous windows,
     // marginalise at the write-out - `1101 both` 79.2 -> 50.0 us at C2 (two histograms with two atomics per start before).
     // Five positions measured WORSE than two histograms (10011 both 145 us, 11101 both 133 us against 68 us for the contiguous
@@ -814,5 +924,10 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
 #undef PO_COUNT_WIDE
     if (lrc) return lrc;
     PO_CHECK_LAUNCH("count_kernel");
+    if (seg) {
+        hipLaunchKernelGGL(seg_rows_sum_kernel, dim3((uint32_t)((n_segs + kSegsPerBlock - 1) / kSegsPerBlock)), dim3(256), 0, ctx->stream,
+                           chunk_start, rec_of_chunk, d_max_chunks, (uint32_t)n_seqs, pat.dim, P.seg_rows, P.seg_tot, d_counts, tot);
+        PO_CHECK_LAUNCH("seg_rows_sum_kernel");
+    }
     return PO_OK;
 }

@@ -63,6 +63,7 @@ struct po_ctx {
     po_buf ws_pq;                      // Kendall's word-pair table, cached per (dim, fold layout, format)
     uint64_t pq_key = ~0ull;
     po_buf ws_thermo;                  // Bray-Curtis thermometer plan (levels per word, element map)
+    po_buf ws_seg;                     // stage 1: segment rows of long records (po_count.hip), all zero between calls
     po_buf ws_fasta;                   // per-block partial results of the on-device FASTA scan (po_fasta.hip)
     const uint8_t* fasta_data = nullptr;   // the buffer po_fasta_scan_dev last sized, with its length and totals
     uint64_t fasta_len = 0, fasta_records = 0, fasta_seq_bytes = 0;

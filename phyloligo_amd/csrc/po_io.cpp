@@ -18,6 +18,9 @@
 #include <atomic>
 #include <charconv>
 #include <functional>
+#include <new>
+#include <stdexcept>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -57,6 +60,39 @@ unsigned po_host_threads(unsigned cap) {
     }();
     return usable < cap ? usable : (cap ? cap : 1u);
 }
+
+namespace {
+// work(t) for t in [0, n) on n host threads, and wait.  When the system refuses a thread (std::system_error) the shares of the
+// threads that could not be started run on the calling thread: no exception leaves through the C ABI and no joinable
+// std::thread is destroyed (that would be std::terminate).
+template <class F>
+void po_run_threads(unsigned n, F&& work) {
+    if (n <= 1) {
+        if (n) work(0u);
+        return;
+    }
+    std::vector<std::thread> pool;
+    unsigned started = 0;
+    try {
+        pool.reserve(n);
+        for (; started < n; ++started) pool.emplace_back(std::ref(work), started);
+    } catch (...) {
+    }
+    for (unsigned t = started; t < n; ++t) work(t);
+    for (auto& th : pool) th.join();
+}
+}  // namespace
+
+// An extern "C" function whose body allocates: std::bad_alloc (or anything else) becomes a status, not an abort of the caller.
+#define PO_C_GUARD_BEGIN try {
+#define PO_C_GUARD_END(name)                                                                     \
+    } catch (const std::bad_alloc&) {                                                            \
+        po_set_error(name ": out of host memory");                                               \
+        return PO_ENOMEM;                                                                        \
+    } catch (const std::exception& e) {                                                          \
+        po_set_error(name ": %s", e.what());                                                     \
+        return PO_EIO;                                                                           \
+    }
 
 namespace {
 
@@ -133,10 +169,7 @@ int fasta_parallel(const uint8_t* data, uint64_t len, uint8_t* seq_out, uint64_t
     std::vector<uint64_t> nrec(nseg, 0), nout(nseg, 0);
     std::vector<int> rcs(nseg, PO_OK);
     auto run = [&](const std::function<void(uint64_t)>& body_fn) {
-        if (nseg == 1) { body_fn(0); return; }
-        std::vector<std::thread> th;
-        for (uint64_t s = 0; s < nseg; ++s) th.emplace_back(body_fn, s);
-        for (auto& t : th) t.join();
+        po_run_threads((unsigned)nseg, [&](unsigned s) { body_fn(s); });
     };
     run([&](uint64_t s) {
         rcs[s] = fasta_walk(data, cut[s], cut[s + 1], true, 0, 0, nullptr, nullptr, nullptr, nullptr, &nrec[s], &nout[s]);
@@ -165,7 +198,9 @@ extern "C" int po_fasta_scan(const uint8_t* data, uint64_t len, uint64_t* n_reco
         po_set_error("po_fasta_scan: NULL argument");
         return PO_EINVAL;
     }
+    PO_C_GUARD_BEGIN
     return fasta_parallel(data, len, nullptr, nullptr, nullptr, nullptr, n_records, seq_bytes);
+    PO_C_GUARD_END("po_fasta_scan")
 }
 
 extern "C" int po_fasta_extract(const uint8_t* data, uint64_t len, uint8_t* seq_out, uint64_t* offsets_out,
@@ -174,7 +209,9 @@ extern "C" int po_fasta_extract(const uint8_t* data, uint64_t len, uint8_t* seq_
         po_set_error("po_fasta_extract: NULL argument");
         return PO_EINVAL;
     }
+    PO_C_GUARD_BEGIN
     return fasta_parallel(data, len, seq_out, offsets_out, title_begin, title_end, nullptr, nullptr);
+    PO_C_GUARD_END("po_fasta_extract")
 }
 
 // The first `len` bytes of a file into buf, read by the host threads the job may use (pread of disjoint ranges):
@@ -182,6 +219,10 @@ extern "C" int po_fasta_extract(const uint8_t* data, uint64_t len, uint8_t* seq_
 extern "C" int po_file_read(const char* path, uint8_t* buf, uint64_t len) {
     if (!path || (!buf && len)) { po_set_error("po_file_read: NULL argument"); return PO_EINVAL; }
     if (len == 0) return PO_OK;
+    unsigned nthr = po_host_threads(16);
+    if (len / (8u << 20) + 1 < nthr) nthr = (unsigned)(len / (8u << 20) + 1);          // at least 8 MiB per thread
+    std::vector<int> rcs;
+    try { rcs.assign(nthr, PO_OK); } catch (const std::bad_alloc&) { po_set_error("po_file_read: out of host memory"); return PO_ENOMEM; }
     const int fd = open(path, O_RDONLY);
     if (fd < 0) { po_set_error("cannot open %s: %s", path, strerror(errno)); return PO_EIO; }
     {   // a freshly allocated destination: ask for huge pages before the reader threads touch it (as in po_api.hip)
@@ -189,10 +230,6 @@ extern "C" int po_file_read(const char* path, uint8_t* buf, uint64_t len) {
         const uintptr_t hi = (reinterpret_cast<uintptr_t>(buf) + len) & ~(uintptr_t)4095u;
         if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
     }
-    unsigned nthr = po_host_threads(16);
-    if (len / (8u << 20) + 1 < nthr) nthr = (unsigned)(len / (8u << 20) + 1);          // at least 8 MiB per thread
-    std::vector<int> rcs(nthr, PO_OK);
-    std::vector<std::thread> pool;
     const uint64_t per = (len + nthr - 1) / nthr;
     auto work = [&](unsigned t) {
         uint64_t at = (uint64_t)t * per;
@@ -203,11 +240,7 @@ extern "C" int po_file_read(const char* path, uint8_t* buf, uint64_t len) {
             at += (uint64_t)got;
         }
     };
-    if (nthr == 1) work(0);
-    else {
-        for (unsigned t = 0; t < nthr; ++t) pool.emplace_back(work, t);
-        for (auto& th : pool) th.join();
-    }
+    po_run_threads(nthr, work);
     close(fd);
     for (int rc : rcs)
         if (rc != PO_OK) { po_set_error("read of %s failed: %s", path, strerror(errno)); return rc; }
@@ -233,6 +266,7 @@ extern "C" int po_pwrite_rows(int fd, const void* src, uint64_t rows, uint64_t r
         while (len) {                                              // pwrite may write less than asked
             const ssize_t w = pwrite(fd, p, len, (off_t)at);
             if (w < 0) { if (errno == EINTR) continue; return errno ? errno : EIO; }
+            if (w == 0) return EIO;                                // no progress and no error: do not spin
             p += w; len -= (uint64_t)w; at += (uint64_t)w;
         }
         return 0;
@@ -242,7 +276,8 @@ extern "C" int po_pwrite_rows(int fd, const void* src, uint64_t rows, uint64_t r
     unsigned nthr = po_host_threads(threads > 0 ? (unsigned)threads : 8u);
     if (total / (4u << 20) + 1 < nthr) nthr = (unsigned)(total / (4u << 20) + 1);      // at least 4 MiB per thread
     if (!contiguous && rows < nthr) nthr = (unsigned)rows;
-    std::vector<int> errs(nthr, 0);
+    std::vector<int> errs;
+    try { errs.assign(nthr, 0); } catch (const std::bad_alloc&) { po_set_error("po_pwrite_rows: out of host memory"); return PO_ENOMEM; }
     auto work = [&](unsigned t) {
         if (contiguous) {
             const uint64_t per = ((total + nthr - 1) / nthr + 4095u) & ~(uint64_t)4095u;   // page-aligned cuts
@@ -254,12 +289,7 @@ extern "C" int po_pwrite_rows(int fd, const void* src, uint64_t rows, uint64_t r
         const uint64_t r0 = std::min<uint64_t>(rows, (uint64_t)t * per), r1 = std::min<uint64_t>(rows, r0 + per);
         for (uint64_t r = r0; r < r1 && !errs[t]; ++r) errs[t] = put(base + r * src_pitch, row_bytes, file_offset + r * file_pitch);
     };
-    if (nthr <= 1) work(0);
-    else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nthr; ++t) pool.emplace_back(work, t);
-        for (auto& th : pool) th.join();
-    }
+    po_run_threads(nthr, work);
     for (int e : errs)
         if (e) { po_set_error("po_pwrite_rows: pwrite failed: %s", strerror(e)); return PO_EIO; }
     return PO_OK;
@@ -286,6 +316,8 @@ int po_ring_copy_rows(const po_ring_source& src, void* const stage[2], size_t st
     std::atomic<uint64_t> ready{0}, done{0};
     std::atomic<bool> failed{false};
     std::vector<std::thread> th;
+    try {
+    th.reserve(n_thr);
     for (unsigned t = 0; t < n_thr; ++t)
         th.emplace_back([&, t]() {
             for (uint64_t c = 0; c < n_chunks; ++c) {
@@ -299,6 +331,12 @@ int po_ring_copy_rows(const po_ring_source& src, void* const stage[2], size_t st
                 done.fetch_add(1, std::memory_order_release);
             }
         });
+    } catch (...) {                                                   // the system refused a thread: the copies need all of them
+        failed.store(true);
+        for (auto& x : th) x.join();
+        po_set_error("po_ring_copy_rows: could not start %u host threads", n_thr);
+        return PO_ENOMEM;
+    }
     int rc = issue(0);
     for (uint64_t c = 0; c < n_chunks && rc == PO_OK; ++c) {
         rc = src.wait(src.user);                                      // chunk c is in its staging buffer
@@ -357,7 +395,12 @@ extern "C" int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, 
         // rows are formatted by a pool of host threads, a slab of rows each, and written in order
         const unsigned nthreads = (rows * cols < (1u << 16)) ? 1u : po_host_threads(32);
         const uint64_t slab = std::max<uint64_t>(1, std::min<uint64_t>((rows + nthreads - 1) / nthreads, (4u << 20) / (cols * 25 + 1) + 1));
-        std::vector<std::vector<char>> bufs(nthreads);
+        std::vector<std::vector<char>> bufs;
+        try { bufs.resize(nthreads); } catch (const std::bad_alloc&) { rc = PO_ENOMEM; }
+        std::atomic<bool> oom{false};                                  // a formatting buffer could not grow (in whichever thread)
+        auto fmt = [&](uint64_t r0, uint64_t r1, std::vector<char>* out) {
+            try { format_rows(m, r0, r1, cols, ld, *out); } catch (...) { oom.store(true); }
+        };
         for (uint64_t base = 0; base < rows && rc == PO_OK; base += slab * nthreads) {
             std::vector<std::thread> pool;
             unsigned used = 0;
@@ -366,15 +409,24 @@ extern "C" int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, 
                 if (r0 >= rows) break;
                 const uint64_t r1 = std::min(rows, r0 + slab);
                 ++used;
-                if (nthreads == 1) format_rows(m, r0, r1, cols, ld, bufs[t]);
-                else pool.emplace_back(format_rows, m, r0, r1, cols, ld, std::ref(bufs[t]));
+                bool started = false;
+                if (nthreads > 1) {
+                    try {
+                        pool.emplace_back(fmt, r0, r1, &bufs[t]);
+                        started = true;
+                    } catch (...) {                                    // no thread to be had: format this slab here
+                    }
+                }
+                if (!started) fmt(r0, r1, &bufs[t]);
             }
             for (auto& th : pool) th.join();
+            if (oom.load()) { rc = PO_ENOMEM; break; }
             for (unsigned t = 0; t < used; ++t)
                 if (fwrite(bufs[t].data(), 1, bufs[t].size(), fh) != bufs[t].size()) { rc = PO_EIO; break; }
         }
     }
-    if (fclose(fh) != 0) rc = PO_EIO;
-    if (rc != PO_OK) po_set_error("write to %s failed: %s", path, strerror(errno));
+    if (fclose(fh) != 0 && rc == PO_OK) rc = PO_EIO;
+    if (rc == PO_ENOMEM) po_set_error("po_write_mat_text: out of host memory while formatting %s", path);
+    else if (rc != PO_OK) po_set_error("write to %s failed: %s", path, strerror(errno));
     return rc;
 }

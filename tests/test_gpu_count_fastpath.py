@@ -94,3 +94,49 @@ def test_long_record_and_windows(ctx):
         oc, ot = oracle.compute_counts([big[int(b):int(e)] for b, e in zip(begins, ends)], pattern, strand)
         assert np.array_equal(counts.astype(np.int64), oc)
         assert np.array_equal(np.asarray(totals).astype(np.int64), np.asarray(ot).astype(np.int64))
+
+
+@pytest.mark.parametrize("pattern,strand,seed", [("1111", "both", 0), ("1111", "both", 1), ("1111", "plus", 2), ("111111", "minus", 3),
+                                                 ("1101", "both", 4), ("11011011", "both", 5), ("1011", "plus", 6), ("1111111", "both", 7)])
+def test_long_records_go_through_segment_rows(ctx, pattern, strand, seed):
+    """Records of more than 512 chunks (~1 Mb) add their workgroups' histograms into scratch rows per 128-chunk segment instead
+    of one row of the count matrix (po_count.hip, kSegChunks; profiles/r04_stage1.txt).  Who owns a segment is decided by its
+    first chunk: two long records back to back, long records that start in the middle of a segment and right behind short ones,
+    a record of exactly 512 / 513 chunks, dirt (N runs, lower case, IUPAC) - all against the oracle, bit for bit, and again in a
+    second call on the same context (the scratch rows have to be zero again) with the records in reverse order."""
+    import torch
+    rng = np.random.default_rng(900 + seed)
+    span = 2016                                                       # window starts per chunk (kChunkSpan)
+    lens = []
+    for _ in range(int(rng.integers(5, 60))):
+        lens.append(int(rng.integers(1, 5000)))
+    lens += [int(rng.integers(1_100_000, 1_400_000)), int(rng.integers(1_050_000, 1_300_000))]      # two long ones back to back
+    lens += [int(rng.integers(1, 3000)) for _ in range(int(rng.integers(1, 40)))]
+    lens += [512 * span + len(pattern) - 1, 7, 512 * span + len(pattern), 513 * span]                  # 512 and 513 chunks
+    lens += [int(rng.integers(2_000_000, 3_000_000))]
+    lens += [int(rng.integers(1, 3000)) for _ in range(3)]
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    recs = []
+    for L in lens:
+        r = alphabet[rng.integers(0, 4, size=L)].copy()
+        for _ in range(max(1, L // 20000)):                               # dirt: N runs, lower case, an IUPAC code
+            a = int(rng.integers(0, L))
+            r[a:a + int(rng.integers(1, 60))] = ord("N")
+            a = int(rng.integers(0, L))
+            r[a:a + int(rng.integers(1, 200))] |= 0x20
+        if L > 10:
+            r[int(rng.integers(0, L))] = ord("R")
+        recs.append(r.tobytes())
+    oc, ot = oracle.compute_counts(recs, pattern, strand)
+
+    def run(order):
+        seq = np.frombuffer(b"".join(recs[i] for i in order), dtype=np.uint8)
+        off = np.concatenate([[0], np.cumsum([len(recs[i]) for i in order])]).astype(np.int64)
+        c, t = ctx.count_profiles(torch.from_numpy(seq.copy()).cuda(), torch.from_numpy(off).cuda(), pattern, strand)
+        return c.cpu().numpy().view(np.uint32).astype(np.int64), t.cpu().numpy().astype(np.int64)
+
+    order = list(range(len(recs)))
+    c, t = run(order)
+    assert np.array_equal(t, ot) and np.array_equal(c, oc)
+    c, t = run(order[::-1])
+    assert np.array_equal(t, ot[::-1]) and np.array_equal(c, oc[::-1])

@@ -12,7 +12,8 @@ ctx = pa.Context(0)
 g = torch.Generator(device="cuda"); g.manual_seed(5)
 lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
 seq = lut[torch.randint(0, 4, (total,), device="cuda", generator=g)]
-for rec_len in (2_000, 20_000, 200_000, 2_000_000, 20_000_000, 200_000_000, total):
+sizes = [int(float(x)) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [2_000, 20_000, 200_000, 2_000_000, 20_000_000, 200_000_000, total]
+for rec_len in sizes:
     n = max(1, total // rec_len)
     off = torch.arange(0, n + 1, dtype=torch.int64, device="cuda") * rec_len
     off[-1] = total
