@@ -104,7 +104,7 @@ typedef struct po_stats {
 #define PO_KERNEL_VALU_JSD 1u
 #define PO_KERNEL_VALU_BC 2u
 #define PO_KERNEL_MFMA_F64_GRAM 3u
-#define PO_KERNEL_MFMA_I8_GRAM 4u  /* exact int8 kernels (counts <= 16383; Spearman ranks, dim <= 8191), else the float64 one */
+#define PO_KERNEL_MFMA_I8_GRAM 4u  /* exact int8 kernels (counts <= 2097151, dim <= 32768; Spearman ranks, dim <= 16384), else the float64 one */
 #define PO_KERNEL_VALU_KT 5u
 #define PO_KERNEL_MFMA_I8_KT 8u /* Kendall tau as an exact matrix-core Gram over pair-sign vectors (FP4 / int8 operands) */
 #define PO_KERNEL_MFMA_BC 9u    /* Bray-Curtis as s_a + s_b - 2 <thermometer(a), thermometer(b)> on the matrix cores   */

@@ -11,7 +11,9 @@
 //     G = 16384 <hi_a,hi_b> + 128 (<hi_a,lo_b> + <lo_a,hi_b>) + <lo_a,lo_b>
 // comes EXACTLY out of v_mfma_i32_32x32x32_i8 (int32 accumulators, combined in float64 below 2^53).
 // One plane covers counts <= 127 (every 2 kb contig at k=4: max 38 measured), two planes cover |v| <= 16383
-// (contigs up to ~1 Mb at k=4; ranks for any D <= 8191).  The int8 MFMA rate is ~60x the float64 one, so the
+// (contigs up to ~1 Mb at k=4; ranks for any D <= 16 384), three planes (counts only, round 4) <= 2 097 151: scaffolds and
+// chromosomes up to ~250 Mb at k=4 - G = sum over s of 128^s * (sum over p + q = s of <digit_p(a), digit_q(b)>), five int32
+// accumulator groups, still exact (G < 2^53 whenever a record's total is below 2^32).  The int8 MFMA rate is ~60x the float64 one, so the
 // matrix-core time is small and the kernel is bound by its epilogue and by writing 16 B per pair.
 //
 // Operand layout (built per call by prep_planes_kernel): plane[p][k/16][record][k%16] - 16-byte K-chunks
@@ -34,6 +36,7 @@ constexpr int KCH = 128;                            // bytes of K per record and
 constexpr int kChunkBytes = 128 * 16;               // one 16-byte K-chunk of the tile's 128 records
 constexpr int kTrStride = 33;                       // transposed 32 x 32 block of a wave, in doubles (odd: conflict free)
 constexpr int kMirrorBytes = 8 * 32 * kTrStride * 8;
+constexpr int kPlanes = 3;                          // digit planes in the workspace (the third one for counts only)
 constexpr int kTermBytes = 6 * 128 * 8;             // per-record terms of the tile's rows and columns, read by the epilogue
 
 // planes[p][q][r][16]: digit p of words 16q..16q+15 of record r;  rs: per-record terms;  *maxabs = max |v|.
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint32_t* __rest
                     if (d0 + e < dim) v[e] = vals[r * dim + d0 + e];
             }
         }
-        uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+        uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0}, top[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int sv = (int)v[e];
@@ -84,10 +87,12 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint32_t* __rest
             sq += (unsigned long long)a * a;
             mx = max(mx, a);
             lo[e >> 2] |= (v[e] & 127u) << (8 * (e & 3));
-            hi[e >> 2] |= ((SIGNED ? (uint32_t)(sv >> 7) : (v[e] >> 7)) & 255u) << (8 * (e & 3));
+            hi[e >> 2] |= (SIGNED ? ((uint32_t)(sv >> 7) & 255u) : ((v[e] >> 7) & 127u)) << (8 * (e & 3));
+            if (!SIGNED) top[e >> 2] |= ((v[e] >> 14) & 127u) << (8 * (e & 3));     // third digit of a count (values < 2^21)
         }
         *reinterpret_cast<uint4*>(planes + ((size_t)q * npad + r) * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         *reinterpret_cast<uint4*>(planes + plane + ((size_t)q * npad + r) * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        if (!SIGNED) *reinterpret_cast<uint4*>(planes + 2 * plane + ((size_t)q * npad + r) * 16) = make_uint4(top[0], top[1], top[2], top[3]);
     }
     if (sq) atomicAdd(&sq_s[rr], sq);
     if (mx) atomicMax(&mx_s[rr], mx);
@@ -122,15 +127,15 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
     }
     extern __shared__ __align__(16) unsigned char smem[];  // staging [P][A|B][8 chunks][128 records][16 B], then the mirror scratch
     const uint32_t t = threadIdx.x;
-    const uint32_t lane = t & 63, wave = t >> 6;
+    const uint32_t lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));   // the wave index as a scalar
     const uint32_t wr = wave >> 1, wc = wave & 1;          // 4 x 2 waves of 32 x 64
     const uint32_t lr = lane & 31, lh = lane >> 5;
     uint32_t ti, tj;
     po_tile_coords(A, TM, blockIdx.x, ti, tj);
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
     const size_t plane = (size_t)A.npad * dpad;
-    constexpr int NG = P == 1 ? 1 : 3;                     // P == 2: [0] hi.hi, [1] hi.lo + lo.hi, [2] lo.lo
-    constexpr int HI = P - 1, LL = NG - 1;
+    constexpr int kStepUnroll = P == 3 ? 1 : KCH / 32;
+    constexpr int NG = 2 * P - 1;                          // g[s]: sum over p + q = s of <digit p of the row, digit q of the column>
 
     v16i g[NG][2];
 #pragma unroll
@@ -151,7 +156,9 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
             po_glds16(src, smem + ((p * 2 + side) * 8 + q) * kChunkBytes + half * 1024);
         }
         __syncthreads();                                   // drains the LDS-DMA (vmcnt) of every wave
-#pragma unroll
+        // (three planes: 160 accumulator registers of the 256 - the k-steps stay a loop, or the operand fragments of all four
+        //  are fetched ahead and the kernel spills)
+#pragma unroll kStepUnroll
         for (int s = 0; s < KCH / 32; ++s) {
             const uint32_t q = 2 * s + lh;                 // lane halves take the two 16-byte chunks of a k-step
             v4i a[P], b[P][2];
@@ -163,16 +170,12 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
                     b[p][nn] = *reinterpret_cast<const v4i*>(smem + ((p * 2 + 1) * 8 + q) * kChunkBytes + (wc * 64 + nn * 32 + lr) * 16);
             }
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn) {
-                if (P == 1) {
-                    g[0][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[0][nn], g[0][nn], 0, 0, 0);
-                } else {
-                    g[0][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[HI], b[HI][nn], g[0][nn], 0, 0, 0);
-                    g[HI][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[HI], b[0][nn], g[HI][nn], 0, 0, 0);
-                    g[HI][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[HI][nn], g[HI][nn], 0, 0, 0);
-                    g[LL][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], b[0][nn], g[LL][nn], 0, 0, 0);
-                }
-            }
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int pa = 0; pa < P; ++pa)
+#pragma unroll
+                    for (int pb = 0; pb < P; ++pb)
+                        g[pa + pb][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pa], b[pb][nn], g[pa + pb][nn], 0, 0, 0);
         }
     }
     __syncthreads();                                       // the staging area becomes the mirror scratch
@@ -207,9 +210,9 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
             const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             const uint64_t r = iw + rl;
             const double trr = t0r[rl], irr = METRIC == PO_EUCL ? t1r[rl] : 0.0;
-            double G;
-            if (P == 1) G = (double)g[0][nn][reg];
-            else G = fma(16384.0, (double)g[0][nn][reg], fma(128.0, (double)g[HI][nn][reg], (double)g[LL][nn][reg]));
+            double G = (double)g[NG - 1][nn][reg];               // Horner in 128: every partial sum an exact integer below 2^53
+#pragma unroll
+            for (int s = NG - 2; s >= 0; --s) G = fma(128.0, G, (double)g[s][nn][reg]);
             double v;
             if (METRIC == PO_EUCL) {
                 const double cross = G * (irr * ic);       // symmetric in (r,c); equals S/n^2 for duplicates
@@ -283,24 +286,24 @@ ws_view view(void* ws, uint64_t npad, uint32_t dim) {
     v.dpad = (uint32_t)po_round_up(dim, KCH);
     uint8_t* base = static_cast<uint8_t*>(ws);
     v.planes = reinterpret_cast<int8_t*>(base);
-    v.rs = reinterpret_cast<double*>(base + 2 * (size_t)npad * v.dpad);
-    v.maxabs = reinterpret_cast<uint32_t*>(base + 2 * (size_t)npad * v.dpad + 3 * npad * sizeof(double));
+    v.rs = reinterpret_cast<double*>(base + kPlanes * (size_t)npad * v.dpad);
+    v.maxabs = reinterpret_cast<uint32_t*>(base + kPlanes * (size_t)npad * v.dpad + 3 * npad * sizeof(double));
     return v;
 }
 
 }  // namespace
 
-// largest |value| two digit planes represent.  The int32 accumulators cannot overflow for any supported
-// dimension: the cross plane adds two products <= 127*127 per word, 2 * 16129 * 65536 < 2^31.
-uint32_t po_gram_i8_value_limit(uint32_t dim) { return dim <= 65536 ? 16383u : 127u; }
-bool po_gram_i8_sc_supported(uint32_t dim) { return dim >= 1 && dim <= 8191; }   // |2 #less + #equal - D| <= D - 1 < 8192
+// largest count the digit planes represent: three (2^21 - 1) where the int32 accumulators hold them - the middle group adds
+// three products <= 127 * 127 per word, 3 * 16129 * 32768 < 2^31 - else two (2 * 16129 * 65536 < 2^31).
+uint32_t po_gram_i8_value_limit(uint32_t dim) { return dim <= 32768 ? 2097151u : (dim <= 65536 ? 16383u : 127u); }
+bool po_gram_i8_sc_supported(uint32_t dim) { return dim >= 1 && dim <= 16384; }  // |2 #less + #equal - D| <= D - 1 <= 16383: two digits, the high one signed
 
 size_t po_gram_i8_workspace(uint64_t n, uint32_t dim) {
     const uint64_t npad = po_round_up(n ? n : 1, 128);
-    return 2 * npad * po_round_up(dim, KCH) + 3 * npad * sizeof(double) + 256;
+    return kPlanes * npad * po_round_up(dim, KCH) + 3 * npad * sizeof(double) + 256;
 }
 
-// ws layout: plane lo | plane hi | rs[3][npad] | maxabs.   signed_values: vals are int32 (SC's r2), else uint32 counts.
+// ws layout: plane lo | plane hi | plane top | rs[3][npad] | maxabs.   signed_values: vals are int32 (SC's r2), else uint32 counts.
 int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_vals, const uint64_t* d_totals, bool signed_values, uint64_t n,
                            uint32_t dim, uint64_t npad, void* ws, const uint32_t** maxabs_out) {
     const ws_view v = view(ws, npad, dim);
@@ -317,7 +320,7 @@ int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_vals, const uint64_t* 
     return PO_OK;
 }
 
-// Eucl: the one-plane kernel (max <= 127) and the two-plane kernel (127 < max <= limit) are both launched;
+// Eucl: the one-, two- and three-plane kernels (max <= 127, <= 16 383, <= limit) are all launched and one of them runs;
 // SC: two planes, unconditionally.
 int po_launch_gram_i8_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const void* ws, uint64_t* tiles) {
     const ws_view v = view(const_cast<void*>(ws), a.npad, a.dim);
@@ -326,6 +329,8 @@ int po_launch_gram_i8_tiles(po_ctx* ctx, int metric, const po_tile_args& a, cons
     int rc = launch_tiles<1, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, -1, 127, tiles);
     if (rc) return rc;
     const uint32_t limit = po_gram_i8_value_limit(a.dim);
-    if (limit > 127) rc = launch_tiles<2, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, 127, limit, nullptr);
+    if (limit > 127) rc = launch_tiles<2, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, 127, limit < 16383u ? limit : 16383u, nullptr);
+    if (rc) return rc;
+    if (limit > 16383) rc = launch_tiles<3, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, 16383, limit, nullptr);
     return rc;
 }

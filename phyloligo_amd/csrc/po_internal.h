@@ -177,7 +177,7 @@ int po_launch_bc_sad_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t*
                           uint64_t npad, void* ws, const unsigned long long** cls_out);
 int po_launch_bc_sad_tiles(po_ctx* ctx, const po_tile_args& a, const void* ws, uint64_t* tiles);
 size_t po_gram_i8_workspace(uint64_t n, uint32_t dim);
-uint32_t po_gram_i8_value_limit(uint32_t dim);       // largest |value| the exact int8 kernels take (two 7-bit digits)
+uint32_t po_gram_i8_value_limit(uint32_t dim);       // largest count the exact int8 kernels take (three 7-bit digits where the accumulators hold them)
 bool po_gram_i8_sc_supported(uint32_t dim);          // Spearman's doubled centred ranks fit two digits
 // digit planes + per-record terms from uint32 counts (Eucl) or int32 doubled centred ranks (SC, signed_values)
 int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_vals, const uint64_t* d_totals, bool signed_values, uint64_t n,

@@ -1,5 +1,6 @@
 """Exact int8-MFMA Gram kernels (csrc/po_gram_i8.hip): Euclidean distance with one digit plane (counts <= 127),
-two digit planes (counts <= 16383) and the float64 kernel beyond that; Spearman from doubled centred ranks."""
+two digit planes (counts <= 16 383), three (counts <= 2 097 151: scaffolds and chromosomes) and the float64 kernel beyond
+that; Spearman from doubled centred ranks."""
 import numpy as np
 import pytest
 
@@ -30,7 +31,8 @@ def random_counts(n, dim, top, seed, empty=(3,), dup=((5, 17),)):
     return counts, counts.sum(1).astype(np.uint64)
 
 
-@pytest.mark.parametrize("top,kernel", [(127, I8), (128, I8), (5000, I8), (16383, I8), (16384, F64), (3_000_000, F64)])
+@pytest.mark.parametrize("top,kernel", [(127, I8), (128, I8), (5000, I8), (16383, I8), (16384, I8), (100_000, I8), (2_097_151, I8),
+                                        (2_097_152, F64), (3_000_000, F64)])
 @pytest.mark.parametrize("dim", [16, 256, 200])
 def test_eucl_digit_planes(ctx, top, kernel, dim):
     counts, totals = random_counts(300, dim, top, seed=top + dim)
@@ -44,14 +46,40 @@ def test_eucl_digit_planes(ctx, top, kernel, dim):
     general = ctx.pairwise(counts, totals, "Eucl", table_path=False)
     np.testing.assert_allclose(general, want, rtol=RTOL, atol=ATOL)
     if kernel == I8 and top > 127:
-        # two planes: G is an exact integer, so the result does not depend on tiling or on the row range
+        # two / three planes: G is an exact integer, so the result does not depend on tiling or on the row range
         sub = ctx.pairwise(counts, totals, "Eucl", row_begin=40, row_end=171)
         assert np.array_equal(sub, got[40:171])
         f32 = ctx.pairwise(counts, totals, "Eucl", dtype="float32")
         assert np.array_equal(f32, got.astype(np.float32))
 
 
-@pytest.mark.parametrize("dim", [4, 64, 256, 1024, 4096])
+@pytest.mark.parametrize("dim", [4096, 16384])
+def test_eucl_three_planes_large_word_space(ctx, dim):
+    """Three digit planes at k = 6 / 7: the middle accumulator group adds three digit products per word, so its worst case -
+    two records with every count at 2 097 151 (all three digits 127) - is 3 x 16 129 x 16 384 = 7.9e8 < 2^31.  Against the
+    oracle; records with totals beyond 2^32 are outside the exact-integer guarantee (G up to 2^56) but not outside rtol."""
+    rng = np.random.default_rng(dim)
+    n = 150
+    counts = rng.integers(0, 700_000, size=(n, dim), dtype=np.uint32)
+    counts[rng.random((n, dim)) < 0.3] = 0
+    counts[0] = 2_097_151
+    counts[1] = 2_097_151
+    counts[1, 1::2] = 1_048_575                # (not a near-duplicate of record 0: a Gram form cannot resolve d^2 below 1e-16 of its terms)
+    counts[2] = 0
+    counts[3, :] = 0
+    counts[3, 7] = 1
+    totals = counts.sum(1).astype(np.uint64)
+    got, st = ctx.pairwise(counts, totals, "Eucl", want_stats=True)
+    assert st["kernel_id"] == I8
+    freq = oracle.counts_to_frequencies(counts.astype(np.int64), totals.astype(np.int64))
+    want = oracle.pairwise_block(freq, "Eucl")
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+    assert np.array_equal(got, got.T) and np.all(np.diag(got) == 0.0)
+    general = ctx.pairwise(counts, totals, "Eucl", table_path=False)           # the float64 Gram on the same input
+    np.testing.assert_allclose(general, got, rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize("dim", [4, 64, 256, 1024, 4096, 16384])
 def test_spearman_int8_vs_float64_kernel_and_scipy(ctx, dim):
     from scipy.stats import spearmanr
     rng = np.random.default_rng(dim)
@@ -77,7 +105,7 @@ def test_spearman_int8_vs_float64_kernel_and_scipy(ctx, dim):
 
 def test_spearman_dimension_beyond_two_digits_uses_float64(ctx):
     rng = np.random.default_rng(1)
-    freq = rng.random((40, 9000))
+    freq = rng.random((12, 16385))
     got, st = ctx.pairwise_freq(freq, "SC", want_stats=True)
     assert st["kernel_id"] == F64
     np.testing.assert_allclose(got, oracle.pairwise_block(freq, "SC"), rtol=RTOL, atol=ATOL)
