@@ -147,3 +147,54 @@ def test_device_ingest_feeds_stage_one(ctx, tmp_path):
     counts, totals = ctx.count_profiles(d_seq, d_off, "1111", "both")
     hc, ht = ctx.count_profiles(seq, off, "1111", "both")
     assert np.array_equal(counts.cpu().numpy().astype(np.uint32), hc) and np.array_equal(totals.cpu().numpy().astype(np.uint64), ht)
+
+
+def test_file_of_more_than_4_gib(ctx, tmp_path):
+    """Maximum sizes of the ingest: a 4.5 GB FASTA file with one record of 3.3 GB wrapped at 80 columns and one of 1.2 GB on a
+    single line (byte positions, record offsets and line lengths beyond 2^32 / 2^31) through the device parser and the host
+    parser: record offsets, titles and every sequence byte as generated.  Needs ~6 GB of disk and ~12 GB of host memory."""
+    import shutil
+    import torch
+    import phyloligo_amd as pa
+    if shutil.disk_usage(tmp_path).free < 8 * (1 << 30):
+        pytest.skip("needs 8 GB of free disk")
+    path = str(tmp_path / "big.fa")
+    rng = np.random.default_rng(3)
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    specs = [("a small one", 1_000_003, 60), ("big wrapped", 3_300_000_017, 80), ("c single line", 1_200_000_000, 0), ("d", 5_001, 70)]
+    seqs = []
+    with open(path, "wb") as fh:
+        for title, L, width in specs:
+            s = alphabet[rng.integers(0, 4, size=L, dtype=np.uint8)]
+            seqs.append(s)
+            fh.write(b">" + title.encode() + b"\n")
+            if width == 0:
+                s.tofile(fh)
+                fh.write(b"\n")
+                continue
+            full = (L // width) * width
+            body = np.empty((L // width, width + 1), dtype=np.uint8)
+            body[:, :width] = s[:full].reshape(-1, width)
+            body[:, width] = 10
+            body.tofile(fh)
+            del body
+            if L > full:
+                s[full:].tofile(fh)
+                fh.write(b"\n")
+    assert os.path.getsize(path) > (1 << 32)
+    want_off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int64)
+    d_seq, d_off, titles = pa.api.fasta_index_dev(ctx, path)
+    assert list(titles) == [t for t, _, _ in specs]
+    assert np.array_equal(d_off.cpu().numpy(), want_off)
+    for i, s in enumerate(seqs):
+        a, b = int(want_off[i]), int(want_off[i + 1])
+        for lo in range(a, b, 1 << 30):
+            hi = min(b, lo + (1 << 30))
+            assert torch.equal(d_seq[lo:hi].cpu(), torch.from_numpy(s[lo - a:hi - a])), (i, lo)
+    del d_seq
+    from phyloligo_amd import phyloligo as cli
+    h_seq, h_off, h_titles = cli.read_fasta(path)
+    assert np.array_equal(np.asarray(h_off, dtype=np.int64), want_off) and list(h_titles) == [t for t, _, _ in specs]
+    for i, s in enumerate(seqs):
+        assert np.array_equal(np.asarray(h_seq[want_off[i]:want_off[i + 1]]), s), i
+    os.remove(path)
