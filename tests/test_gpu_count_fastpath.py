@@ -97,7 +97,8 @@ def test_long_record_and_windows(ctx):
 
 
 @pytest.mark.parametrize("pattern,strand,seed", [("1111", "both", 0), ("1111", "both", 1), ("1111", "plus", 2), ("111111", "minus", 3),
-                                                 ("1101", "both", 4), ("11011011", "both", 5), ("1011", "plus", 6), ("1111111", "both", 7)])
+                                                 ("1101", "both", 4), ("11011011", "both", 5), ("1011", "plus", 6), ("1111111", "both", 7),
+                                                 ("110100111", "both", 8), ("1" + "0" * 38 + "11", "both", 9), ("10000000000000000000000000000011", "minus", 10)])
 def test_long_records_go_through_segment_rows(ctx, pattern, strand, seed):
     """Records of more than 512 chunks (~1 Mb) add their workgroups' histograms into scratch rows per 128-chunk segment instead
     of one row of the count matrix (po_count.hip, kSegChunks; profiles/r04_stage1.txt).  Who owns a segment is decided by its
