@@ -75,6 +75,39 @@ def test_memmap_container(fasta, tmp_path):
     assert np.allclose(raw.reshape(n, n), g["JSD_1111_both"], atol=1e-3)      # the reference's own criterion
 
 
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_memmap_container_over_an_existing_file(fasta, tmp_path, ranks):
+    """An output path that already holds a file - longer, shorter, or of exactly the new size - is reused without being emptied
+    first (O_TRUNC on a cached 10 GB container costs as much as writing it): the result must be the same bytes and the same
+    length as into a new file, from one process and from two ranks."""
+    import subprocess
+    import sys
+    from phyloligo_amd import phyloligo as P
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path, g = fasta
+    fresh = tmp_path / "fresh.f32"
+    args = ["-i", path, "-p", "1111", "-d", "BC", "--method", "joblib", "--large", "memmap"]
+
+    def run(out):
+        if ranks == 1:
+            P.main(args + ["-o", str(out)])
+        else:
+            env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+            env.update(PO_CLI_REHEARSAL="1", MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT)
+            r = subprocess.run([sys.executable, "-m", "phyloligo_amd", "--gpus", "2"] + args + ["-o", str(out)], capture_output=True,
+                               text=True, timeout=600, cwd=ROOT, env=env)
+            assert r.returncode == 0, r.stderr[-2000:]
+
+    run(fresh)
+    want = fresh.read_bytes()
+    assert len(want) == g["BC_1111_both"].size * 4
+    for name, old in (("longer", b"\xff" * (len(want) + 12345)), ("shorter", b"\xff" * 1000), ("same", b"\xff" * len(want))):
+        out = tmp_path / (name + ".f32")
+        out.write_bytes(old)
+        run(out)
+        assert out.read_bytes() == want, name
+
+
 def _read_memmap_like_comparemat(path):
     """phyloligo_comparemat.py:16-24 restated: float32 memmap, N = sqrt(len), weird shapes rejected"""
     matrix = np.memmap(path, dtype=np.float32, mode="r")
