@@ -109,6 +109,18 @@ def test_mat_text_is_numpy_savetxt(tmp_path, golden_dir):
     assert path.read_bytes() == buf.getvalue()
     pa.write_mat_text(path, x[:2], append=True)
     assert path.read_bytes() == buf.getvalue() + buf.getvalue()[:len(buf.getvalue().split(b"\n")[0]) * 0 + sum(len(l) + 1 for l in buf.getvalue().split(b"\n")[:2])]
+    # an existing file is overwritten in place (no O_TRUNC: that costs as much as the write on a large cached file) and cut
+    # to the new length; a matrix large enough for several rounds of slabs on several threads, written over a longer file
+    big = rng.standard_normal((700, 900)) * 10.0 ** rng.integers(-5, 5, (700, 900))
+    path.write_bytes(b"x" * 30_000_000)
+    pa.write_mat_text(path, big)
+    buf = io.BytesIO()
+    np.savetxt(buf, big, delimiter="\t")
+    assert path.read_bytes() == buf.getvalue()
+    pa.write_mat_text(path, x)                                          # and a short one over the long one
+    buf = io.BytesIO()
+    np.savetxt(buf, x, delimiter="\t")
+    assert path.read_bytes() == buf.getvalue()
 
 
 def test_cli_resolution_matches_reference(golden_dir):
