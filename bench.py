@@ -146,6 +146,7 @@ def path_lines(ctx, seq, offsets, counts, totals, n, dim, metric, pattern, dev, 
     import subprocess
     import tempfile
     import torch
+    from phyloligo_amd import api
     from phyloligo_amd import phyloligo as P
     from phyloligo_amd import synthetic
     lines = {"workload": "%d contigs, dim %d, -d %s" % (n, dim, metric), "stage1_ms": stage1_ms, "matrix_ms": matrix_ms,
@@ -213,6 +214,18 @@ def path_lines(ctx, seq, offsets, counts, totals, n, dim, metric, pattern, dev, 
         os.remove(out)
         del freq
         ctx.trim()
+        # the reference's default output: the text .mat (numpy.savetxt layout) of a 6 000 x 6 000 corner of the matrix, twice
+        # (the second write goes over the existing file: no first-touch of new page-cache pages)
+        m = np.random.default_rng(7).random((6000, 6000))
+        txt = os.path.join(tmp, "corner.mat")
+        for key in ("mat_text_first_write_s", "mat_text_write_s"):
+            t0 = time.perf_counter()
+            api.write_mat_text(txt, m)
+            lines[key] = time.perf_counter() - t0
+        lines["mat_text_bytes"] = os.path.getsize(txt)
+        lines["mat_text_gb_per_s"] = lines["mat_text_bytes"] / lines["mat_text_write_s"] / 1e9
+        os.remove(txt)
+        del m
         env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         cmd = [sys.executable, "-m", "phyloligo_amd", "-i", fa, "-p", pattern, "-d", metric, "--method", "joblib", "--large", "memmap",
                "-o", out, "-w", tmp]

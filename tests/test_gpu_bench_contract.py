@@ -50,6 +50,7 @@ def test_bench_json_contract():
         assert pl[key] is not None and pl[key] >= 0 or key == "container_write_ms", (key, pl)
     assert pl["e2e_cli_rc"] == 0 and pl["e2e_cli_container_bytes"] == 3000 * 3000 * 4 == pl["container_bytes"] == pl["d2h_bytes"]
     assert abs(pl["matrix_ms"] - r["ms_per_step"]) < 1e-9
+    assert pl["mat_text_bytes"] > 6000 * 6000 * 24 and pl["mat_text_gb_per_s"] > 0.5       # the text .mat writer (reference default output)
 
 
 def test_bench_multi_rank_path_rehearsal():
