@@ -127,6 +127,39 @@ def test_rank_statistics_histogram_and_comparison_paths_agree(ctx):
         assert np.array_equal(from_counts, from_freq, equal_nan=True), metric
 
 
+def test_frequency_input_of_long_contigs_is_recovered_by_continued_fractions(ctx):
+    """Round 4: a long contig has no rare word - its smallest count is in the hundreds or thousands - and the round-1 recovery
+    (total = m / smallest frequency for m <= 255) gave up on it, which sent the WHOLE matrix to the float64 kernels (Eucl 12.1
+    instead of 5.1 ms on the ragged assembly).  The total now comes out of the continued fraction of a frequency (exact integer
+    Euclid on the mantissa), verified bit for bit as before: records with smallest counts 300 .. 40 000 and totals up to 3e7,
+    a record whose counts all share a factor with the total (comes back in lowest terms), a record with one word, an empty one
+    and short records next to them - the exact int8 kernels run (two and three digit planes) and give what the counts give."""
+    rng = np.random.default_rng(11)
+    n, dim = 200, 256
+    counts = rng.integers(0, 60, size=(n, dim), dtype=np.uint32)                 # short records: smallest count 0 / 1
+    counts[0:40] = rng.integers(300, 2000, size=(40, dim))                           # ~200 kb contigs
+    counts[40:60] = rng.integers(5_000, 16_000, size=(20, dim))                      # ~1 Mb
+    counts[60:70] = rng.integers(40_000, 120_000, size=(10, dim))                    # ~10 Mb: three digit planes
+    counts[70] = 6 * rng.integers(50, 500, size=dim)                                 # every count a multiple of 6 (and so is the total)
+    counts[71] = 0
+    counts[72] = 0
+    counts[72, 17] = 123_457
+    counts[73] = counts[5]                                                           # a duplicate of a long record
+    totals = counts.sum(1).astype(np.uint64)
+    assert totals.max() > 2e7
+    freq = ctx.frequencies(counts, totals)
+    for metric, kid in (("Eucl", I8), ("SC", I8), ("KT", 8)):
+        want, st_c = ctx.pairwise(counts, totals, metric, want_stats=True)
+        got, st_f = ctx.pairwise_freq(freq, metric, want_stats=True)
+        assert st_f["kernel_id"] == st_c["kernel_id"] == kid, (metric, st_f["kernel_id"])
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15, equal_nan=True)
+    got = ctx.pairwise_freq(freq, "Eucl")
+    assert got[5, 73] == 0.0 and got[73, 5] == 0.0
+    general = ctx.pairwise_freq(freq, "Eucl", table_path=False)
+    np.testing.assert_allclose(got, general, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(got, oracle.pairwise_block(freq, "Eucl"), rtol=RTOL, atol=ATOL)
+
+
 def test_frequency_input_recovers_the_integer_profiles(ctx):
     """po_pairwise_freq (the reference's own argument type): frequencies that are count / total are traced back to
     the integers - verified bit for bit on the device - and take the same exact kernels as the count entry point;
