@@ -465,7 +465,8 @@ def main():
                        "rc_folded": rc_folded,      # strand-symmetric profiles summed over one word per {w, rc(w)} orbit
                        "equal_total_table_path": main_kernel_id == 6,
                        "table_path_needs": "every 128-record block to share one word total and counts <= 127 (fixed-length "
-                                           "contigs, windows, reads); otherwise jsd_general_kernel_only is the rate",
+                                           "contigs, windows, reads; counts 128 .. 255 take the table's wide layout at ~1.4 x the "
+                                           "time); otherwise jsd_general_kernel_only is the rate",
                        "jsd_general_kernel_only": general,
                        "env_knobs": knobs},
             "roofline": roof,

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void rc_fold_kernel(const T* __restrict__ in, 
             const unsigned long long tot = totals[row], ref = totals[0];
             const bool common = tot > 0 && tot == ref;
             uint32_t bits = 0;
-            if (!(common && sum_s[r] == tot && max_s[r] <= 127u)) bits |= PO_FOLD_NOT_ALL_TABLE;
+            if (!(common && sum_s[r] == tot && max_s[r] <= 255u)) bits |= PO_FOLD_NOT_ALL_TABLE;   // po_jsd_lut.hip: kWideMax
             if (!(common && max_s[r] <= 255u)) bits |= PO_FOLD_NOT_ALL_SAD;
             if (fold_some_equal(totals, row, n, tot)) bits |= PO_FOLD_SOME_EQUAL;
             // (read first: on a uniform assembly EVERY record reports PO_FOLD_SOME_EQUAL, and 50 000 atomics on one address
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void rc_fold_long_kernel(const T* __restrict__
             const unsigned long long tot = totals[row], ref = totals[0];
             const bool common = tot > 0 && tot == ref;
             uint32_t bits = 0;
-            if (!(common && sum == tot && mx <= 127u)) bits |= PO_FOLD_NOT_ALL_TABLE;
+            if (!(common && sum == tot && mx <= 255u)) bits |= PO_FOLD_NOT_ALL_TABLE;
             if (!(common && mx <= 255u)) bits |= PO_FOLD_NOT_ALL_SAD;
             if (fold_some_equal(totals, row, n, tot)) bits |= PO_FOLD_SOME_EQUAL;
             // (read first: on a uniform assembly EVERY record reports PO_FOLD_SOME_EQUAL, and 50 000 atomics on one address

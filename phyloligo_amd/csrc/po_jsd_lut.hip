@@ -24,14 +24,28 @@ namespace {
 constexpr int TM = 128, TN = 128;
 constexpr int kLutEntries = 256;                       // sums 0..255  -> counts up to 127 (fixed-length contigs up to ~10 kb at k=4)
 constexpr int kLutBytes = kLutEntries * 256;           // 32 copies x 8 B per entry
+// Round 4, the WIDE layout of the same 64 KiB: 512 entries x 16 copies (sums 0..511 -> counts up to 255: fixed-length records
+// of 10 .. 20 kb at k=4, e.g. a genome cut into windows).  Lanes l and l + 16 of a 32-lane LDS pass then share a copy (a 2-way
+// bank conflict when they read different entries), which is still several times cheaper than the float64-logarithm kernel such an
+// input used to fall back to.  The layout is chosen on the device from the largest count: prep_counts_kernel<false> writes the
+// operands for the narrow layout and finds the maximum, prep_counts_kernel<true> rewrites them for the wide one iff
+// 127 < max <= 255 (it leaves at once otherwise), the table is laid out accordingly; the tile kernel only ever adds a row term
+// and a column term and is the same for both.
+constexpr uint32_t kNarrowMax = 127, kWideMax = 255;
 constexpr double LN2 = 0.693147180559945309417232121458;
 
 // Ct[d][npad] = counts[n][d] << 8 (uint32, transposed, zero padded to D8 x npad)
 // ctb (may be NULL): the same with the byte offset of the table copy of the lane that will look the column up baked in:
 // column record j is looked up by lane (j >> 1) & 63 of a wave, which uses copy (j >> 1) & 31 (8 bytes each)
+template <bool WIDE>
 __global__ __launch_bounds__(256) void prep_counts_kernel(const uint32_t* __restrict__ counts, uint64_t n, uint32_t dim,
                                                           uint64_t npad, uint32_t* __restrict__ ct, uint32_t* __restrict__ ctb,
                                                           uint32_t* __restrict__ maxcount) {
+    if (WIDE) {                                                   // second pass: only when the first one found 127 < max <= 255
+        const uint32_t m = *maxcount;
+        if (m <= kNarrowMax || m > kWideMax) return;
+    }
+    constexpr uint32_t SHIFT = WIDE ? 7u : 8u, COPY_MASK = WIDE ? 15u : 31u;
     __shared__ uint32_t tile[64][65];
     __shared__ uint32_t blkmax;
     const uint64_t n0 = (uint64_t)blockIdx.x * 64;
@@ -44,16 +58,18 @@ __global__ __launch_bounds__(256) void prep_counts_kernel(const uint32_t* __rest
         const uint64_t row = n0 + r;
         const uint32_t v = (row < n && d0 + tx < dim) ? counts[row * dim + d0 + tx] : 0u;
         mx = max(mx, v);
-        tile[r][tx] = v << 8;
+        tile[r][tx] = v << SHIFT;
     }
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(&blkmax, mx);
+    if (!WIDE) {
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, o, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(&blkmax, mx);
+    }
     __syncthreads();
-    if (threadIdx.x == 0 && blkmax > *maxcount) atomicMax(maxcount, blkmax);   // racy pre-check skips redundant atomics
+    if (!WIDE && threadIdx.x == 0 && blkmax > *maxcount) atomicMax(maxcount, blkmax);   // racy pre-check skips redundant atomics
     for (uint32_t r = ty; r < 64; r += 4)
         if (d0 + r < ((dim + 7u) & ~7u) && n0 + tx < npad) {
             ct[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r];
-            if (ctb) ctb[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r] + ((((uint32_t)(n0 + tx) >> 1) & 31u) << 3);
+            if (ctb) ctb[(uint64_t)(d0 + r) * npad + n0 + tx] = tile[tx][r] + ((((uint32_t)(n0 + tx) >> 1) & COPY_MASK) << 3);
         }
 }
 
@@ -73,16 +89,18 @@ __global__ __launch_bounds__(128) void classify_kernel(const unsigned long long*
     const bool ok = (r >= n) || (totals[r] == ref && fabs(wsum[r] - 1.0) < 1e-9);
     const int all = __syncthreads_and(ok ? 1 : 0);
     if (threadIdx.x == 0) {
-        const bool table = all && ref > 0 && 2u * *maxcount < (uint32_t)kLutEntries;
+        const bool table = all && ref > 0 && *maxcount <= kWideMax;
         cls[blockIdx.x] = table ? ref : 0ull;
         clsk[blockIdx.x] = table ? make_double2(1.0 / (double)ref, 2.0 * log((double)ref)) : make_double2(0.0, 0.0);
     }
 }
 
-// the table as the tile kernels want it in LDS: entry x replicated 32 times (copy c at x*32 + c)
-__global__ void lut_table_kernel(double* __restrict__ lut) {
-    const uint32_t x = blockIdx.x;
-    lut[x * 32 + threadIdx.x] = x ? (double)x * log((double)x) : 0.0;
+// the table as the tile kernels want it in LDS: entry x replicated 32 times (copy c at x*32 + c) - or, in the wide layout,
+// 512 entries replicated 16 times (copy c at x*16 + c): the same 8 192 doubles either way
+__global__ void lut_table_kernel(double* __restrict__ lut, const uint32_t* __restrict__ maxcount) {
+    const uint32_t g = blockIdx.x * 32 + threadIdx.x;
+    const uint32_t x = *maxcount > kNarrowMax ? g >> 4 : g >> 5;
+    lut[g] = x ? (double)x * log((double)x) : 0.0;
 }
 
 
@@ -391,9 +409,10 @@ int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t
     double2* clsk = reinterpret_cast<double2*>(base + kLutBytes + 256 + po_round_up(dim, 8) * npad * sizeof(uint32_t));
     PO_HIP(hipMemsetAsync(maxcount, 0, sizeof(uint32_t), ctx->stream));
     dim3 grid((uint32_t)(npad / 64), (dim + 63) / 64);
-    hipLaunchKernelGGL(prep_counts_kernel, grid, dim3(256), 0, ctx->stream, d_counts, n, dim, npad, ct, ctb, maxcount);
+    hipLaunchKernelGGL(prep_counts_kernel<false>, grid, dim3(256), 0, ctx->stream, d_counts, n, dim, npad, ct, ctb, maxcount);
+    hipLaunchKernelGGL(prep_counts_kernel<true>, grid, dim3(256), 0, ctx->stream, d_counts, n, dim, npad, ct, ctb, maxcount);
     PO_CHECK_LAUNCH("prep_counts_kernel");
-    hipLaunchKernelGGL(lut_table_kernel, dim3(kLutEntries), dim3(32), 0, ctx->stream, lut);
+    hipLaunchKernelGGL(lut_table_kernel, dim3(kLutEntries), dim3(32), 0, ctx->stream, lut, maxcount);
     PO_CHECK_LAUNCH("lut_table_kernel");
     hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, ctx->stream,
                        reinterpret_cast<const unsigned long long*>(d_totals), n, maxcount, d_wsum, cls, clsk);

@@ -165,6 +165,36 @@ def test_jsd_table_kernel_covers_counts_up_to_127(ctx):
     np.testing.assert_allclose(table, po.pairwise_block(freq, "JSD"), rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("length,strand,lo,hi", [(12_000, "both", 128, 255), (16_000, "both", 128, 255), (20_000, "plus", 100, 255),
+                                                 (26_000, "both", 256, 100000)])
+def test_jsd_table_kernel_wide_layout_counts_up_to_255(ctx, length, strand, lo, hi):
+    """Round 4: fixed-length records of 10 .. 20 kb (a genome cut into windows) have counts of 128 .. 255; the table kernel
+    takes them with its wide layout (512 entries x 16 copies, chosen on the device from the largest count) instead of handing
+    the matrix to the float64-logarithm kernel.  kernel id 6, against the general kernel and the oracle; a largest count beyond
+    255 (last case) still goes to the general kernel, and a narrow call after a wide one on the same context gets the narrow
+    layout back (the operands and the table are rebuilt per call)."""
+    from oracle import phyloligo_oracle as po
+    from phyloligo_amd import synthetic
+    seq, off = synthetic.contig_bytes(300, length, seed=length)
+    counts, totals = ctx.count_profiles(seq, off, "1111", strand)
+    assert lo <= counts.max() <= hi and totals.min() == totals.max()
+    table, st = ctx.pairwise(counts, totals, "JSD", want_stats=True)
+    general = ctx.pairwise(counts, totals, "JSD", table_path=False)
+    np.testing.assert_allclose(table, general, rtol=1e-9, atol=1e-13)
+    if counts.max() <= 255:
+        assert st["kernel_id"] == 6 and not np.array_equal(table, general)        # the table kernel did the work
+    else:
+        assert np.array_equal(table, general)                                      # nobody but the general kernel
+    freq = po.counts_to_frequencies(counts.astype(np.int64), totals.astype(np.int64))
+    np.testing.assert_allclose(table, po.pairwise_block(freq, "JSD"), rtol=RTOL, atol=ATOL)
+    assert np.array_equal(table, table.T) and np.all(np.diag(table) == 0.0)
+    seq2, off2 = synthetic.contig_bytes(300, 2000, seed=1)
+    c2, t2 = ctx.count_profiles(seq2, off2, "1111", "both")
+    narrow, st2 = ctx.pairwise(c2, t2, "JSD", want_stats=True)
+    assert st2["kernel_id"] == 6
+    np.testing.assert_allclose(narrow, ctx.pairwise(c2, t2, "JSD", table_path=False), rtol=1e-9, atol=1e-13)
+
+
 def test_trim_gives_workspaces_back_and_calls_keep_working():
     """po_ctx_trim frees every grown device workspace (the materialised Kendall operand included); the next call
     allocates again and gives the same bits; a call for another metric releases a pair-dot operand above 1 GB by itself."""
