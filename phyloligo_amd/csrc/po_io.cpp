@@ -12,6 +12,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -399,8 +400,12 @@ extern "C" int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, 
         po_set_error("cannot open %s: %s", path, strerror(errno));
         return PO_EIO;
     }
+    // A regular file takes its slabs by pwrite at their places; anything else (/dev/stdout into a pipe, a FIFO, /dev/null) gets
+    // them in order through write() from one thread, as numpy.savetxt would.
+    struct stat sb;
+    const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
     uint64_t at = 0;                                               // where the next byte goes
-    if (append) {
+    if (append && regular) {
         const off_t end = lseek(fd, 0, SEEK_END);
         if (end < 0) { po_set_error("cannot seek in %s: %s", path, strerror(errno)); close(fd); return PO_EIO; }
         at = (uint64_t)end;
@@ -411,7 +416,7 @@ extern "C" int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, 
         // before it, known as soon as THAT one is formatted - so a thread formats, waits for its place (the chain runs through
         // slabs taken earlier, by threads that wait for nothing later), hands the next place on and pwrites, while the others
         // are formatting: no round structure, no serial write.
-        const unsigned nthreads = (rows * cols < (1u << 16)) ? 1u : po_host_threads(32);
+        const unsigned nthreads = (rows * cols < (1u << 16) || !regular) ? 1u : po_host_threads(32);
         const uint64_t slab = std::max<uint64_t>(1, std::min<uint64_t>((rows + nthreads - 1) / nthreads, (8u << 20) / (cols * 25 + 1) + 1));
         const uint64_t n_slabs = (rows + slab - 1) / slab;
         constexpr uint64_t NOT_YET = ~0ull;
@@ -440,7 +445,7 @@ extern "C" int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, 
                     const char* p = bufs[t].data();
                     uint64_t len = bufs[t].size();
                     while (len) {
-                        const ssize_t w = pwrite(fd, p, len, (off_t)off);
+                        const ssize_t w = regular ? pwrite(fd, p, len, (off_t)off) : write(fd, p, len);
                         if (w < 0 && errno == EINTR) continue;
                         if (w <= 0) { failed.store(w < 0 && errno ? errno : EIO); return; }
                         p += w; len -= (uint64_t)w; off += (uint64_t)w;
@@ -453,7 +458,7 @@ extern "C" int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, 
             else at = place[n_slabs].load();
         }
     }
-    if (rc == PO_OK && ftruncate(fd, (off_t)at) != 0) { rc = PO_EIO; io_errno = errno; }     // an older, longer file ends here
+    if (rc == PO_OK && regular && ftruncate(fd, (off_t)at) != 0) { rc = PO_EIO; io_errno = errno; }     // an older, longer file ends here
     if (close(fd) != 0 && rc == PO_OK) { rc = PO_EIO; io_errno = errno; }
     if (rc == PO_ENOMEM) po_set_error("po_write_mat_text: out of host memory while formatting %s", path);
     else if (rc != PO_OK) po_set_error("write to %s failed: %s", path, strerror(io_errno));

@@ -123,6 +123,25 @@ def test_mat_text_is_numpy_savetxt(tmp_path, golden_dir):
     assert path.read_bytes() == buf.getvalue()
 
 
+def test_mat_text_into_a_pipe_and_dev_null(tmp_path):
+    """Not every -o is a regular file: a FIFO (what `-o /dev/stdout | ...` is) gets the rows in order through write(), /dev/null
+    is not truncated (ftruncate fails there) - both worked with numpy.savetxt and keep working."""
+    import threading
+    rng = np.random.default_rng(3)
+    m = rng.standard_normal((400, 300))
+    fifo = str(tmp_path / "pipe")
+    os.mkfifo(fifo)
+    got = []
+    reader = threading.Thread(target=lambda: got.append(open(fifo, "rb").read()))
+    reader.start()
+    pa.write_mat_text(fifo, m)
+    reader.join(30)
+    buf = io.BytesIO()
+    np.savetxt(buf, m, delimiter="\t")
+    assert got and got[0] == buf.getvalue()
+    pa.write_mat_text("/dev/null", m)
+
+
 def test_cli_resolution_matches_reference(golden_dir):
     z = np.load(os.path.join(golden_dir, "cli.npz"))
     for k in z.files:
