@@ -109,7 +109,7 @@ typedef struct po_stats {
 #define PO_KERNEL_MFMA_I8_KT 8u /* Kendall tau as an exact matrix-core Gram over pair-sign vectors (FP4 / int8 operands) */
 #define PO_KERNEL_MFMA_BC 9u    /* Bray-Curtis as s_a + s_b - 2 <thermometer(a), thermometer(b)> on the matrix cores   */
 #define PO_KERNEL_SAD_BC 7u    /* packed-byte SAD kernel (equal-total blocks) + general kernel for the rest */
-#define PO_KERNEL_LUT_JSD 6u   /* integer-sum table kernel + general kernel for the remaining tiles */
+#define PO_KERNEL_LUT_JSD 6u   /* integer-sum table kernel (equal-total blocks, counts <= 255) + general kernel for the remaining tiles */
 
 /* ---- library / context ------------------------------------------------------------------ */
 const char* po_version(void);   /* "phyloligo_amd 0.1 (gfx950) src <16 hex digits>": the hash of the sources it was built from */
@@ -246,7 +246,9 @@ int po_fasta_extract_dev(po_ctx* ctx, const uint8_t* d_data, uint64_t len, uint8
                          uint64_t* d_title_begin, uint64_t* d_title_end);
 
 /* numpy.savetxt(path, m, delimiter="\t") of bin/phyloligo.py:1061,1066: "%.18e" values, '\t'
- * between columns, '\n' after each row, "nan"/"inf" spelled as numpy spells them.            */
+ * between columns, '\n' after each row, "nan"/"inf" spelled as numpy spells them.  A regular file that exists is
+ * overwritten in place and cut to the new length at the end (append = 1: continued at its end); the rows are formatted and
+ * written by the host threads the job may use.  Any other kind of file (pipe, /dev/null) gets the bytes in order.          */
 int po_write_mat_text(const double* m, uint64_t rows, uint64_t cols, uint64_t ld, const char* path, int append);
 
 /* The write side of the raw float32 container of `--large memmap` (bin/phyloligo.py:394-427: row slices assigned into a
