@@ -44,6 +44,7 @@ def test_c4_plan_covers_every_pair_once_host():
 def c4():
     import torch
     import phyloligo_amd as pa
+    torch.cuda.empty_cache()                                   # what earlier tests left in torch's cache is not "used"
     free, total = torch.cuda.mem_get_info()
     if total < 100e9:
         pytest.skip("needs ~60 GB of HBM")
@@ -136,6 +137,7 @@ def test_config4_assembly_on_one_gpu_float32():
     from phyloligo_amd import synthetic
     from oracle import phyloligo_oracle as po
     n = 200_000
+    torch.cuda.empty_cache()                                   # what earlier tests left in torch's cache is not "used"
     free, _ = torch.cuda.mem_get_info()
     if free < 175 * (1 << 30):
         pytest.skip("needs 175 GB of free HBM")

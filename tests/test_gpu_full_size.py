@@ -264,6 +264,7 @@ def test_profiles_of_more_than_4_gib_of_sequence(ctx, pattern, strand, big):
     ('both' = the record and its reverse complement as one string: 2 L - W + 1, phyloligo.py:141); row sums are the totals; the long
     record's counts equal a histogram of its words computed by torch in pieces (plus strand, contiguous words)."""
     import torch
+    torch.cuda.empty_cache()                                   # what earlier tests left in torch's cache is not "used"
     free, _ = torch.cuda.mem_get_info()
     if free < 40 * (1 << 30):
         pytest.skip("needs ~40 GB of free HBM")
