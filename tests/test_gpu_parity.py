@@ -232,6 +232,50 @@ def test_tournament_blocks_virtual_ranks(ctx, metric, world):
     assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(full, nan=-1.0))
 
 
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", ["eucl_three_planes", "jsd_wide_table"])
+def test_tournament_blocks_virtual_ranks_round4_kernels(ctx, case, world):
+    """The same check for the two kernel variants of round 4, from synthetic counts: Eucl with counts far beyond two int8 digits
+    (three planes) and JSD on equal-total records with counts of 128 .. 255 (the table's wide layout, next to a stretch of
+    mixed totals for the general kernel) - the rank-by-rank work lists assemble to the single-GPU matrix bit for bit."""
+    import torch
+    from phyloligo_amd.dist import RowBlockPlan, assemble_virtual
+    rng = np.random.default_rng(31 + world)
+    n, dim = 650, 256
+    if case == "eucl_three_planes":
+        metric, kid = "Eucl", 4
+        counts = rng.integers(0, 60, size=(n, dim)).astype(np.uint32)
+        counts[40:80] = rng.integers(20_000, 900_000, size=(40, dim))
+        counts[300] = 0
+        counts[301] = counts[41]
+    else:
+        metric, kid = "JSD", 6
+        base = rng.multinomial(16_000, np.full(dim, 1.0 / dim), size=n).astype(np.uint32)       # totals 16 000, counts ~62 +- 8
+        base[:, 0] += 150                                                                           # one word at ~200: wide layout
+        counts = base
+        counts[:, 2] = 0
+        counts[:, 2] = (16_150 + 50 - counts.sum(1)).astype(np.uint32)                             # equal totals again (16 200)
+        counts[384:500] = rng.integers(0, 90, size=(116, dim))                                      # mixed totals: general kernel
+    totals = counts.sum(1).astype(np.uint64)
+    if case == "jsd_wide_table":
+        assert len(set(totals[:384].tolist())) == 1 and 127 < counts.max() <= 255
+    dc, dt = torch.from_numpy(counts.view(np.int32)).cuda(), torch.from_numpy(totals.view(np.int64)).cuda()
+    full, st = ctx.pairwise(dc, dt, metric, want_stats=True)
+    assert st["kernel_id"] == kid
+    plan = RowBlockPlan(n, world)
+    slabs, mirrors = [], []
+    for g in range(world):
+        slab, mir = plan.allocate(g, dc.device, torch.float64)
+        slab.fill_(float("nan"))
+        plan.compute(ctx, dc, dt, metric, g, slab, mir)
+        slabs.append(slab)
+        mirrors.append(mir)
+    got = assemble_virtual(plan, slabs, mirrors)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.isnan(got), torch.isnan(full))
+    assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(full, nan=-1.0))
+
+
 def test_eucl_int8_and_float64_mfma_paths(ctx):
     """Profiles <= 127 take the exact int8-MFMA kernel, larger counts the float64-MFMA kernel; both against
     the oracle, plus the forced general path on the small-count data."""
