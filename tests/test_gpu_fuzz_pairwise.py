@@ -32,9 +32,11 @@ def rc_perm(dim):
 def make_case(rng):
     n = int(rng.choice([1, 2, 5, 64, 127, 128, 129, 200, 257, 300]))
     dim = int(rng.choice([1, 3, 4, 16, 50, 64, 256]))
-    top = int(rng.choice([1, 3, 40, 127, 128, 255, 256, 20000]))
+    top = int(rng.choice([1, 3, 40, 127, 128, 200, 255, 256, 20000, 1_500_000]))     # ... 200: wide JSD table; 1.5e6: three int8 planes
     counts = rng.integers(0, top + 1, size=(n, dim)).astype(np.uint32)
     counts[rng.random((n, dim)) < rng.choice([0.0, 0.3, 0.9])] = 0
+    if rng.random() < 0.2:                                       # no rare word (a long contig): the frequency entry point has to
+        counts = counts + np.uint32(rng.integers(256, 2000))     # find the total by continued fractions
     if dim in (4, 16, 64, 256) and rng.random() < 0.5:          # strand-symmetric records
         counts = counts + counts[:, rc_perm(dim)]
     if rng.random() < 0.5 and n > 2:                             # equal totals: top up one word per record
