@@ -39,6 +39,7 @@ def test_bench_json_contract():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert r["value"] > 100 * cb["value"]
     assert cb["cores"] <= cb["host_cpus_visible"] and cb["c1_full"]["metric_calls"] == 1000000
+    assert 0 < cb["c1_full"]["same_job_on_the_gpu"]["whole_s"] < cb["c1_full"]["distances_s"]       # BASELINE config 1 on both sides
     assert r["config"]["env_knobs"] == {k: v for k, v in os.environ.items() if k.startswith("PO_")}
     gen = r["config"]["jsd_general_kernel_only"]
     assert gen["roofline"]["frac"] > 0 and gen["pairs_per_s"] < r["value"] * 1.5
