@@ -112,6 +112,8 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint32_t* __rest
         uint32_t m = 0;
         for (int i = 0; i < 16; ++i) m = max(m, mx_s[i]);
         if (m > *maxabs) atomicMax(maxabs, m);            // racy pre-check only skips redundant atomics
+        uint32_t* blk = maxabs + 1 + (blockIdx.x >> 3);   // largest |value| of this workgroup's block of 128 records
+        if (m > *blk) atomicMax(blk, m);
     }
 }
 
@@ -135,6 +137,15 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
     const size_t plane = (size_t)A.npad * dpad;
     constexpr int kStepUnroll = P == 3 ? 1 : KCH / 32;
+    // Three planes: which of them a tile needs is decided by ITS two blocks of records (largest count of each, written by the
+    // prep kernel behind *maxabs) - in a real assembly a handful of long contigs need the third digit, most blocks need one -
+    // and the planes a block does not need are neither staged nor multiplied (wave-uniform branches; their accumulators stay 0).
+    uint32_t pr = P, pc = P;
+    if (P == 3 && maxabs != nullptr) {
+        const uint32_t mr = maxabs[1 + ti], mc = maxabs[1 + tj];
+        pr = mr <= 127u ? 1u : (mr <= 16383u ? 2u : 3u);
+        pc = mc <= 127u ? 1u : (mc <= 16383u ? 2u : 3u);
+    }
     constexpr int NG = 2 * P - 1;                          // g[s]: sum over p + q = s of <digit p of the row, digit q of the column>
 
     v16i g[NG][2];
@@ -151,6 +162,7 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
         for (int u = 0; u < 4 * P; ++u) {                  // 32 P one-KiB LDS-DMA instructions, 4 P per wave
             const uint32_t idx = wave * 4 * P + u;
             const uint32_t p = idx >> 5, side = (idx >> 4) & 1, q = (idx >> 1) & 7, half = idx & 1;
+            if (P == 3 && p >= (side ? pc : pr)) continue;  // a digit plane that is all zero for this block of records
             const uint64_t rec = (side ? j0 : i0) + half * 64 + lane;
             const int8_t* src = planes + p * plane + ((size_t)(k0 / 16 + q) * A.npad + rec) * 16;
             po_glds16(src, smem + ((p * 2 + side) * 8 + q) * kChunkBytes + half * 1024);
@@ -164,10 +176,13 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
             v4i a[P], b[P][2];
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                a[p] = *reinterpret_cast<const v4i*>(smem + ((p * 2 + 0) * 8 + q) * kChunkBytes + (wr * 32 + lr) * 16);
+                if (P != 3 || (uint32_t)p < pr)
+                    a[p] = *reinterpret_cast<const v4i*>(smem + ((p * 2 + 0) * 8 + q) * kChunkBytes + (wr * 32 + lr) * 16);
+                if (P != 3 || (uint32_t)p < pc) {
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn)
-                    b[p][nn] = *reinterpret_cast<const v4i*>(smem + ((p * 2 + 1) * 8 + q) * kChunkBytes + (wc * 64 + nn * 32 + lr) * 16);
+                    for (int nn = 0; nn < 2; ++nn)
+                        b[p][nn] = *reinterpret_cast<const v4i*>(smem + ((p * 2 + 1) * 8 + q) * kChunkBytes + (wc * 64 + nn * 32 + lr) * 16);
+                }
             }
 #pragma unroll
             for (int nn = 0; nn < 2; ++nn)
@@ -175,7 +190,8 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
                 for (int pa = 0; pa < P; ++pa)
 #pragma unroll
                     for (int pb = 0; pb < P; ++pb)
-                        g[pa + pb][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pa], b[pb][nn], g[pa + pb][nn], 0, 0, 0);
+                        if (P != 3 || ((uint32_t)pa < pr && (uint32_t)pb < pc))
+                            g[pa + pb][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pa], b[pb][nn], g[pa + pb][nn], 0, 0, 0);
         }
     }
     __syncthreads();                                       // the staging area becomes the mirror scratch
@@ -300,14 +316,14 @@ bool po_gram_i8_sc_supported(uint32_t dim) { return dim >= 1 && dim <= 16384; } 
 
 size_t po_gram_i8_workspace(uint64_t n, uint32_t dim) {
     const uint64_t npad = po_round_up(n ? n : 1, 128);
-    return kPlanes * npad * po_round_up(dim, KCH) + 3 * npad * sizeof(double) + 256;
+    return kPlanes * npad * po_round_up(dim, KCH) + 3 * npad * sizeof(double) + 256 + (npad / 128) * sizeof(uint32_t);
 }
 
-// ws layout: plane lo | plane hi | plane top | rs[3][npad] | maxabs.   signed_values: vals are int32 (SC's r2), else uint32 counts.
+// ws layout: plane lo | plane hi | plane top | rs[3][npad] | maxabs | largest |value| of every block of 128 records.   signed_values: vals are int32 (SC's r2), else uint32 counts.
 int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_vals, const uint64_t* d_totals, bool signed_values, uint64_t n,
                            uint32_t dim, uint64_t npad, void* ws, const uint32_t** maxabs_out) {
     const ws_view v = view(ws, npad, dim);
-    PO_HIP(hipMemsetAsync(v.maxabs, 0, sizeof(uint32_t), ctx->stream));
+    PO_HIP(hipMemsetAsync(v.maxabs, 0, (1 + npad / 128) * sizeof(uint32_t), ctx->stream));
     const dim3 grid((uint32_t)(npad / 16));
     if (signed_values)
         hipLaunchKernelGGL(prep_planes_kernel<true>, grid, dim3(256), 0, ctx->stream, d_vals, nullptr, n, dim, v.dpad, npad,
