@@ -313,34 +313,3 @@ def test_hdf5_container_without_h5py(tmp_path):
         hdf5.read_f32_dataset(str(path), "frequencies")
     assert hdf5.create_f32_dataset(str(tmp_path / "e.h5"), "distances", 0, 0) == 0
     assert hdf5.read_f32_dataset(str(tmp_path / "e.h5"), "distances").shape == (0, 0)
-
-
-def test_comparemat_mirror_reads_all_three_formats(tmp_path, capsys):
-    """phyloligo_amd.comparemat = phyloligo_comparemat.py (reference :1-51): text .mat, raw float32 container and the HDF5
-    "distances" container against each other, the reference's criterion (allclose, atol 1e-3) and its output lines."""
-    from phyloligo_amd import comparemat, hdf5
-    rng = np.random.default_rng(2)
-    m = rng.random((23, 23))
-    m = (m + m.T) / 2
-    np.fill_diagonal(m, 0.0)
-    txt, raw, h5 = tmp_path / "m.mat", tmp_path / "m.f32", tmp_path / "m.h5"
-    pa.write_mat_text(str(txt), m)
-    m.astype(np.float32).tofile(raw)
-    assert comparemat.main(["--mat1", str(txt), "--format1", "numpy", "--mat2", str(raw), "--format2", "memmap"]) == 0
-    out = capsys.readouterr().out.splitlines()
-    assert out[0] == "matrix {}, shape: (23, 23)".format(txt) and out[1] == "matrix {}, shape: (23, 23)".format(raw)
-    assert out[2] == "Identical matrices?: True"
-    if hdf5.available():
-        base = hdf5.create_f32_dataset(str(h5), "distances", 23, 23)
-        with open(h5, "r+b") as fh:
-            fh.seek(base)
-            fh.write(m.astype(np.float32).tobytes())
-        assert comparemat.main(["--mat1", str(h5), "--format1", "h5py", "--mat2", str(txt), "--format2", "numpy"]) == 0
-        assert capsys.readouterr().out.splitlines()[2] == "Identical matrices?: True"
-    (m.astype(np.float32) + np.float32(0.01)).tofile(raw)
-    comparemat.main(["--mat1", str(txt), "--format1", "numpy", "--mat2", str(raw), "--format2", "memmap"])
-    assert capsys.readouterr().out.splitlines()[2] == "Identical matrices?: False"
-    np.zeros(10, dtype=np.float32).tofile(raw)                       # 10 entries: not a square
-    with pytest.raises(SystemExit) as e:
-        comparemat.main(["--mat1", str(raw), "--format1", "memmap", "--mat2", str(raw), "--format2", "memmap"])
-    assert e.value.code == 1
