@@ -117,6 +117,166 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint32_t* __rest
     }
 }
 
+// The distance of a row record and a column record from their exact integer Gram entry G (shared by both tile kernels, so
+// that every path gives the same bits).  Per-record terms - Eucl: t0 = S/n^2, t1 = 1/n, t2 = S (exact);  SC: t0 = N.
+//   Eucl: d^2 = (t0_r + t0_c) + G * ((-2 t1_r) * t1_c): the doubling is exact, so the product of the two per-record factors is
+//   the same number whichever record is the row, and one fused multiply-add replaces multiply, doubling and subtraction
+//   (round 5; five float64 instructions per pair instead of seven).  `same`: the pair is a record with itself.
+template <int METRIC>
+__device__ __forceinline__ double gram_i8_value(const double G, const double t0r, const double t1r, const double* t2r,
+                                                const double t0c, const double t1c, const double* t2c, const bool same) {
+#if defined(PO_EXP_NOMATH)
+    return G * t0c + t0r;                                  // isolating build: the stores without the distance arithmetic
+#endif
+    if (METRIC == PO_EUCL) {
+        const double sum = t0r + t0c;
+        double d2 = fmax(fma(G, (-2.0 * t1r) * t1c, sum), 0.0);
+        if (d2 <= 1.0e-13 * sum) {
+            // cancellation level: are the two count vectors proportional, i.e. the frequency vectors identical
+            // (distance exactly 0 in the reference)?  Cauchy-Schwarz equality G^2 == S_r S_c, tested exactly
+            // with error-free products (all three are integers below 2^53).
+            const double sr = *t2r, sc = *t2c;
+            const double p = G * G, pe = fma(G, G, -p), q = sr * sc, qe = fma(sr, sc, -q);
+            if (p == q && pe == qe) d2 = 0.0;
+        }
+        const double v = po_sqrt_nonneg(d2);
+        return same ? 0.0 : v;
+    } else {                                               // SC; a constant record has N = 0 -> NaN as SciPy gives
+        // G / sqrt(N_r N_c) as G * rsqrt: v_rsq_f64 seed + two Newton steps (~1 ulp) instead of the
+        // ~40-instruction sqrt + divide; identical records (G = N_r = N_c, exact integers) give exactly 0
+        const double x = t0r * t0c;
+        double y = __builtin_amdgcn_rsq(x);
+        y = fma(0.5 * y, fma(-(x * y), y, 1.0), y);
+        y = fma(0.5 * y, fma(-(x * y), y, 1.0), y);
+        return (G == t0r && G == t0c) ? (x > 0.0 ? 0.0 : G / x) : 1.0 - G * y;
+    }
+}
+
+// The same values without their rare cases, N pairs at a time and step by step across the N (no branch, no load): bit i of the
+// result is set where gram_i8_value has to be asked instead - a squared distance at cancellation level (or exactly 0: the square
+// root below has no zero guard), identical rank vectors.  A branch per pair keeps every pair's ~20 dependent float64
+// instructions in a basic block of their own; written like this, N independent chains are in flight in one wave, which is what
+// two waves per SIMD need to keep the vector ALU busy (gram_i8_stream_kernel).  Where its bit is clear a result equals
+// gram_i8_value's bit for bit.
+template <int METRIC, int N>
+__device__ __forceinline__ uint32_t gram_i8_values_fast(const double (&G)[N], const double (&t0r)[N], const double (&t1r)[N],
+                                                        const double (&t0c)[N], const double (&t1c)[N], float (&out)[N]) {
+    uint32_t special = 0;
+#if defined(PO_EXP_NOMATH)
+#pragma unroll
+    for (int e = 0; e < N; ++e) out[e] = (float)(G[e] * t0c[e] + t0r[e]);
+    return 0;
+#endif
+    double x[N], y[N];
+    if (METRIC == PO_EUCL) {
+        double gg[N], h[N], r[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const double sum = t0r[e] + t0c[e];
+            x[e] = fmax(fma(G[e], (-2.0 * t1r[e]) * t1c[e], sum), 0.0);
+            special |= (x[e] <= 1.0e-13 * sum) ? (1u << e) : 0u;
+        }
+#pragma unroll
+        for (int e = 0; e < N; ++e) y[e] = __builtin_amdgcn_rsq(x[e]);      // po_sqrt_nonneg without its x == 0 case
+#pragma unroll
+        for (int e = 0; e < N; ++e) { gg[e] = x[e] * y[e]; h[e] = 0.5 * y[e]; }
+#pragma unroll
+        for (int e = 0; e < N; ++e) r[e] = fma(-h[e], gg[e], 0.5);
+#pragma unroll
+        for (int e = 0; e < N; ++e) { gg[e] = fma(gg[e], r[e], gg[e]); h[e] = fma(h[e], r[e], h[e]); }
+#pragma unroll
+        for (int e = 0; e < N; ++e) r[e] = fma(-gg[e], gg[e], x[e]);
+#pragma unroll
+        for (int e = 0; e < N; ++e) out[e] = (float)fma(r[e], h[e], gg[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) { x[e] = t0r[e] * t0c[e]; special |= (G[e] == t0r[e] && G[e] == t0c[e]) ? (1u << e) : 0u; }
+#pragma unroll
+        for (int e = 0; e < N; ++e) y[e] = __builtin_amdgcn_rsq(x[e]);
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int e = 0; e < N; ++e) y[e] = fma(0.5 * y[e], fma(-(x[e] * y[e]), y[e], 1.0), y[e]);
+#pragma unroll
+        for (int e = 0; e < N; ++e) out[e] = (float)(1.0 - G[e] * y[e]);
+    }
+    asm volatile("" : "+v"(special));                      // the comparisons are made here, not collected at the end of the caller
+    return special;
+}
+
+// The values of a 32 x 64 block of a wave - records rrow .. rrow + 31 of the tile's rows (scratch rows trow ..), columns
+// 64 wc .. - from its accumulators into the float32 tile scratch `tl` (po_tiles.h).  Accumulator layout (32x32): column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  kIlpRows rows
+// = 2 kIlpRows pairs are in flight at a time (every pair holds ~10 registers); the rare cases follow wave by wave.
+// terms: [t0 rows | t0 cols | t1 rows | t1 cols | t2 rows | t2 cols] of the tile's 128 + 128 records (LDS).
+template <int P, int METRIC, int kIlpRows>
+__device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1][2], const double* terms, const uint32_t rrow,
+                                                       const uint32_t trow, const uint32_t wc, const uint32_t lr, const uint32_t lh,
+                                                       const bool diag_tile, float* tl) {
+    constexpr int NG = 2 * P - 1;
+    const double* t0r = terms + rrow, *t0c = terms + 128 + wc * 64;             // Eucl: S/n^2      SC: N
+    const double* t1r = terms + 256 + rrow, *t1c = terms + 384 + wc * 64;       // Eucl: 1/n
+    const double* t2r = terms + 512 + rrow, *t2c = terms + 640 + wc * 64;       // Eucl: S
+    float* wt = tl + (trow + 4 * lh) * kF32TileStride + wc * 64 + lr;
+    const double tc0 = t0c[lr], tc1 = t0c[32 + lr];
+    const double ic0 = METRIC == PO_EUCL ? t1c[lr] : 0.0, ic1 = METRIC == PO_EUCL ? t1c[32 + lr] : 0.0;
+    auto gram = [&](const int nn, const int reg) -> double {
+        double G = (double)g[NG - 1][nn][reg];         // Horner in 128: every partial sum an exact integer below 2^53
+#pragma unroll
+        for (int s = NG - 2; s >= 0; --s) G = fma(128.0, G, (double)g[s][nn][reg]);
+        return G;
+    };
+    uint32_t special = 0;
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += kIlpRows) {
+        double G[2 * kIlpRows], a0[2 * kIlpRows], a1[2 * kIlpRows], b0[2 * kIlpRows], b1[2 * kIlpRows];
+        float v[2 * kIlpRows];
+#pragma unroll
+        for (int e = 0; e < kIlpRows; ++e) {
+            const int reg = r0 + e;
+            const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            G[2 * e] = gram(0, reg); G[2 * e + 1] = gram(1, reg);
+            a0[2 * e] = a0[2 * e + 1] = t0r[rl];
+            a1[2 * e] = a1[2 * e + 1] = METRIC == PO_EUCL ? t1r[rl] : 0.0;
+            b0[2 * e] = tc0; b0[2 * e + 1] = tc1;
+            b1[2 * e] = ic0; b1[2 * e + 1] = ic1;
+        }
+        special |= gram_i8_values_fast<METRIC, 2 * kIlpRows>(G, a0, a1, b0, b1, v);
+#pragma unroll
+        for (int e = 0; e < kIlpRows; ++e) {
+            const int reg = r0 + e;
+            float* wp = wt + ((reg & 3) + 8 * (reg >> 2)) * kF32TileStride;
+            wp[0] = v[2 * e];
+            wp[32] = v[2 * e + 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the rare cases, wave by wave: a pair at cancellation level somewhere in the wave's block, or the diagonal of the matrix
+    if (diag_tile || __builtin_amdgcn_ballot_w64(special != 0) != 0) {
+        // (everything is derived again from the accumulators, behind a barrier the compiler cannot see through: values shared
+        //  with the straight-line pass above would stay live across it - 32 Gram entries and 32 row terms are 128 registers)
+        asm volatile("" ::: "memory");
+        auto gram_again = [&](const int nn, const int reg) -> double {
+            double G = 0.0;
+#pragma unroll
+            for (int s = NG - 1; s >= 0; --s) {
+                int digit_sum = g[s][nn][reg];
+                asm volatile("" : "+v"(digit_sum));
+                G = s == NG - 1 ? (double)digit_sum : fma(128.0, G, (double)digit_sum);
+            }
+            return G;
+        };
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            const double trr = t0r[rl], irr = METRIC == PO_EUCL ? t1r[rl] : 0.0;
+            float* wp = wt + ((reg & 3) + 8 * (reg >> 2)) * kF32TileStride;
+            wp[0] = (float)gram_i8_value<METRIC>(gram_again(0, reg), trr, irr, t2r + rl, tc0, ic0, t2c + lr, diag_tile && rrow + rl == wc * 64 + lr);
+            wp[32] = (float)gram_i8_value<METRIC>(gram_again(1, reg), trr, irr, t2r + rl, tc1, ic1, t2c + 32 + lr, diag_tile && rrow + rl == wc * 64 + 32 + lr);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // P digit planes; runs iff  run_above < *maxabs <= run_upto  (maxabs == nullptr: always).
 template <int P, int METRIC, typename OUT>
 __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(po_tile_args A, const int8_t* __restrict__ planes,
@@ -197,74 +357,327 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
     __syncthreads();                                       // the staging area becomes the mirror scratch
     // per-record terms into LDS: on gfx9 loads and stores share one in-order counter (vmcnt), so a global load
     // issued among the output stores could only be waited for together with every store before it
-    double* terms = reinterpret_cast<double*>(smem + kMirrorBytes);      // [t0 rows | t0 cols | t1 rows | t1 cols]
-    if (t < 256) {
-        const uint64_t rec = (t < 128) ? i0 + t : j0 + (t - 128);
-        terms[t] = rs[rec];
-        terms[256 + t] = METRIC == PO_EUCL ? rs[A.npad + rec] : 0.0;
-        terms[512 + t] = METRIC == PO_EUCL ? rs[2 * A.npad + rec] : 0.0;
+    // (lane coordinates derived again: anything per-lane that lives across the matrix-core loop is spilled at the register limit)
+    uint32_t lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const uint32_t t_e = wave * 64u + lane_e, lr_e = lane_e & 31, lh_e = lane_e >> 5;
+    constexpr bool F32 = sizeof(OUT) == 4;                 // float32 output: the whole tile goes through LDS (po_store_tile_f32)
+    double* terms = reinterpret_cast<double*>(smem + (F32 ? kF32TileBytes : kMirrorBytes));   // [t0 rows | t0 cols | t1 rows | t1 cols]
+    if (t_e < 256) {
+        const uint64_t rec = (t_e < 128) ? i0 + t_e : j0 + (t_e - 128);
+        terms[t_e] = rs[rec];
+        terms[256 + t_e] = METRIC == PO_EUCL ? rs[A.npad + rec] : 0.0;
+        terms[512 + t_e] = METRIC == PO_EUCL ? rs[2 * A.npad + rec] : 0.0;
     }
     __syncthreads();
 
-    // ---- epilogue: accumulator layout (32x32): column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-    OUT* out = static_cast<OUT*>(A.out);
-    OUT* mir = static_cast<OUT*>(A.mirror);
+    // ---- epilogue: accumulator layout (32x32): column = lane_e & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane_e >> 5)
     const bool mirror = po_tile_mirrors(A, ti, tj);
-    const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
     const uint64_t iw = i0 + wr * 32, jw = j0 + wc * 64;
-    double* wl = reinterpret_cast<double*>(smem) + wave * (32 * kTrStride);
     const double* t0r = terms + wr * 32, *t0c = terms + 128 + wc * 64;          // Eucl: S/n^2      SC: N
     const double* t1r = terms + 256 + wr * 32, *t1c = terms + 384 + wc * 64;    // Eucl: 1/n
     const double* t2r = terms + 512 + wr * 32, *t2c = terms + 640 + wc * 64;    // Eucl: S
+    // the distance of row record iw + rl and column record jw + cl from their exact integer Gram entry
+    const bool diag_tile = ti == tj;
+    auto value = [&](const double G, const uint32_t rl, const uint32_t cl, const double tc, const double ic) -> double {
+        return gram_i8_value<METRIC>(G, t0r[rl], METRIC == PO_EUCL ? t1r[rl] : 0.0, t2r + rl, tc, ic, t2c + cl,
+                                     diag_tile && wr * 32 + rl == wc * 64 + cl);
+    };
+    auto gram = [&](const int nn, const int reg) -> double {
+        double G = (double)g[NG - 1][nn][reg];             // Horner in 128: every partial sum an exact integer below 2^53
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
-        const uint64_t c = jw + nn * 32 + lr;
-        const double tc = t0c[nn * 32 + lr], ic = METRIC == PO_EUCL ? t1c[nn * 32 + lr] : 0.0;
-        const bool c_ok = c >= A.col_begin && c < n_cols;
+        for (int s = NG - 2; s >= 0; --s) G = fma(128.0, G, (double)g[s][nn][reg]);
+        return G;
+    };
+    if constexpr (F32) {
+        // every value once into the tile-shaped LDS scratch (no global address, no bounds test per element), one barrier,
+        // then 16-byte stores of whole 512-byte row pieces for the tile and for its transpose
+        float* tl = reinterpret_cast<float*>(smem);
+        gram_i8_values_to_tile<P, METRIC, 2>(g, terms, wr * 32, wr * 32, wc, lr_e, lh_e, diag_tile, tl);
+        po_lds_barrier();
+        po_store_tile_f32<kThreads / 64>(A, mirror, i0, j0, wave, lane_e, tl);
+    } else {
+        OUT* out = static_cast<OUT*>(A.out);
+        OUT* mir = static_cast<OUT*>(A.mirror);
+        const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
+        double* wl = reinterpret_cast<double*>(smem) + wave * (32 * kTrStride);
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            const uint64_t r = iw + rl;
-            const double trr = t0r[rl], irr = METRIC == PO_EUCL ? t1r[rl] : 0.0;
-            double G = (double)g[NG - 1][nn][reg];               // Horner in 128: every partial sum an exact integer below 2^53
+        for (int nn = 0; nn < 2; ++nn) {
+            const uint64_t c = jw + nn * 32 + lr_e;
+            const double tc = t0c[nn * 32 + lr_e], ic = METRIC == PO_EUCL ? t1c[nn * 32 + lr_e] : 0.0;
+            const bool c_ok = c >= A.col_begin && c < n_cols;
 #pragma unroll
-            for (int s = NG - 2; s >= 0; --s) G = fma(128.0, G, (double)g[s][nn][reg]);
-            double v;
-            if (METRIC == PO_EUCL) {
-                const double cross = G * (irr * ic);       // symmetric in (r,c); equals S/n^2 for duplicates
-                double d2 = fmax((trr + tc) - 2.0 * cross, 0.0);
-                if (d2 <= 1.0e-13 * (trr + tc)) {
-                    // cancellation level: are the two count vectors proportional, i.e. the frequency vectors identical
-                    // (distance exactly 0 in the reference)?  Cauchy-Schwarz equality G^2 == S_r S_c, tested exactly
-                    // with error-free products (all three are integers below 2^53).
-                    const double sr = t2r[rl], sc = t2c[nn * 32 + lr];
-                    const double p = G * G, pe = fma(G, G, -p), q = sr * sc, qe = fma(sr, sc, -q);
-                    if (p == q && pe == qe) d2 = 0.0;
+            for (int reg = 0; reg < 16; ++reg) {
+                const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh_e;
+                const uint64_t r = iw + rl;
+                const double v = value(gram(nn, reg), rl, nn * 32 + lr_e, tc, ic);
+                if (c_ok && r >= A.row_begin && r < n_rows) po_out_store(&out[(r - A.row_begin) * A.ld_out + (c - A.col_begin)], (OUT)v);
+                if (mirror) wl[lr_e * kTrStride + rl] = v;
+            }
+            if (mirror) {                                  // wave-private scratch; LDS operations of a wave run in order
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const uint32_t jr = it * 2 + lh_e;
+                    const double w = wl[jr * kTrStride + lr_e];
+                    const uint64_t cm = jw + nn * 32 + jr, r = iw + lr_e;
+                    if (cm >= A.col_begin && cm < n_cols && r >= A.row_begin && r < n_rows)
+                        po_out_store(&mir[(cm - A.col_begin) * A.ld_mirror + (r - A.row_begin)], (OUT)w);
                 }
-                v = po_sqrt_nonneg(d2);
-                if (r == c) v = 0.0;
-            } else {                                       // SC; a constant record has N = 0 -> NaN as SciPy gives
-                // G / sqrt(N_r N_c) as G * rsqrt: v_rsq_f64 seed + two Newton steps (~1 ulp) instead of the
-                // ~40-instruction sqrt + divide; identical records (G = N_r = N_c, exact integers) give exactly 0
-                const double x = trr * tc;
-                double y = __builtin_amdgcn_rsq(x);
-                y = fma(0.5 * y, fma(-(x * y), y, 1.0), y);
-                y = fma(0.5 * y, fma(-(x * y), y, 1.0), y);
-                v = (G == trr && G == tc) ? (x > 0.0 ? 0.0 : G / x) : 1.0 - G * y;
             }
-            if (c_ok && r >= A.row_begin && r < n_rows) po_out_store(&out[(r - A.row_begin) * A.ld_out + (c - A.col_begin)], (OUT)v);
-            if (mirror) wl[lr * kTrStride + rl] = v;
         }
-        if (mirror) {                                      // wave-private scratch; LDS operations of a wave run in order
+    }
+}
+
+// ---- float32 output, one digit plane: four waves of 64 x 64 pairs, four workgroups per CU (round 5) ---------------------
+// The phases of a tile - operands in, matrix cores, ~20 float64 instructions per pair, scratch, stores out - use different
+// parts of the CU and follow each other inside a workgroup; what overlaps them is OTHER workgroups of the CU.  The eight-wave
+// kernel above has two per CU (72 KiB of LDS each).  This one has four: 256 lanes, a wave holds 2 x 2 accumulator blocks (64
+// registers; a third less LDS operand traffic per matrix instruction), and the float32 scratch holds HALF a tile (33 KiB): row
+// block bi of wave row wr covers the tile's rows 64 bi + 32 wr .., so "block 0 of every wave" is the tile's upper half and
+// "block 1" the lower one, and the epilogue makes two passes - values of one half into the scratch, barrier, stores
+// (po_store_tile_f32<4, 64>), barrier.  39 KiB of LDS, at most 128 registers.
+constexpr int kQuadThreads = 256;
+constexpr int kQuadScratchBytes = 64 * kF32TileStride * 4;             // 33 280 B (the 32 KiB staging area lies underneath)
+constexpr int kQuadLdsBytes = kQuadScratchBytes + kTermBytes;
+
+template <int METRIC>
+__global__ __launch_bounds__(kQuadThreads, 4) void gram_i8_quad_kernel(po_tile_args A, const int8_t* __restrict__ planes, uint32_t dpad,
+                                                                       const double* __restrict__ rs, const uint32_t* __restrict__ maxabs,
+                                                                       long long run_above, long long run_upto) {
+    if (maxabs != nullptr) {
+        const long long m = *maxabs;
+        if (m <= run_above || m > run_upto) return;
+    }
+    extern __shared__ __align__(16) unsigned char smem[];  // staging [A|B][8 chunks][128 records][16 B], then the scratch; terms behind
+    const uint32_t t = threadIdx.x;
+    const uint32_t lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
+    const uint32_t wr = wave >> 1, wc = wave & 1;          // 2 x 2 waves of 64 x 64
+    const uint32_t lr = lane & 31, lh = lane >> 5;
+    uint32_t ti, tj;
+    po_tile_coords(A, TM, blockIdx.x, ti, tj);
+    const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
+
+    v16i g[2][1][2];                                       // [row block bi][plane sum][column block]
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const uint32_t jr = it * 2 + lh;
-                const double w = wl[jr * kTrStride + lr];
-                const uint64_t cm = jw + nn * 32 + jr, r = iw + lr;
-                if (cm >= A.col_begin && cm < n_cols && r >= A.row_begin && r < n_rows)
-                    po_out_store(&mir[(cm - A.col_begin) * A.ld_mirror + (r - A.row_begin)], (OUT)w);
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) g[bi][0][nn][e] = 0;
+
+    for (uint32_t k0 = 0; k0 < dpad; k0 += KCH) {
+        __syncthreads();                                   // the previous step's operand reads are done
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                      // 32 one-KiB LDS-DMA instructions, 8 per wave
+            const uint32_t idx = wave * 8 + u;
+            const uint32_t side = (idx >> 4) & 1, q = (idx >> 1) & 7, half = idx & 1;
+            const uint64_t rec = (side ? j0 : i0) + half * 64 + lane;
+            po_glds16(planes + ((size_t)(k0 / 16 + q) * A.npad + rec) * 16, smem + (side * 8 + q) * kChunkBytes + half * 1024);
+        }
+        __syncthreads();                                   // drains the LDS-DMA (vmcnt) of every wave
+#pragma unroll
+        for (int s = 0; s < KCH / 32; ++s) {
+            const uint32_t q = 2 * s + lh;                 // lane halves take the two 16-byte chunks of a k-step
+            v4i a[2], b[2];
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) a[bi] = *reinterpret_cast<const v4i*>(smem + q * kChunkBytes + (bi * 64 + wr * 32 + lr) * 16);
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) b[nn] = *reinterpret_cast<const v4i*>(smem + (8 + q) * kChunkBytes + (wc * 64 + nn * 32 + lr) * 16);
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) g[bi][0][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[bi], b[nn], g[bi][0][nn], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                       // the staging area becomes the scratch
+    // (lane coordinates derived again: anything per-lane that lives across the matrix-core loop is spilled at the register limit)
+    uint32_t lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const uint32_t t_e = wave * 64u + lane_e, lr_e = lane_e & 31, lh_e = lane_e >> 5;
+    float* tl = reinterpret_cast<float*>(smem);
+    double* terms = reinterpret_cast<double*>(smem + kQuadScratchBytes);
+    {
+        const uint64_t rec = (t_e < 128) ? i0 + t_e : j0 + (t_e - 128);
+        terms[t_e] = rs[rec];
+        terms[256 + t_e] = METRIC == PO_EUCL ? rs[A.npad + rec] : 0.0;
+        terms[512 + t_e] = METRIC == PO_EUCL ? rs[2 * A.npad + rec] : 0.0;
+    }
+    const bool mirror = po_tile_mirrors(A, ti, tj);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        po_lds_barrier();                                  // terms in place (h = 0); the stores of the upper half have read the scratch (h = 1)
+        gram_i8_values_to_tile<1, METRIC, 2>(g[h], terms, h * 64 + wr * 32, wr * 32, wc, lr_e, lh_e, ti == tj, tl);
+        po_lds_barrier();
+        po_store_tile_f32<kQuadThreads / 64, 64>(A, mirror, i0 + h * 64, j0, wave, lane_e, tl);
+    }
+}
+
+// ---- float32 output: one persistent workgroup per CU, a loader wave, stores that are never waited for (round 5) ----------
+// With a float32 matrix the tile kernel above has as much float64 arithmetic per byte stored as store time: isolating builds at
+// 200 000 records (160 GB) take 23.6 ms without the global stores and 28.4 ms without the distance arithmetic, the kernel 38.5 -
+// the two phases of a workgroup follow each other, and only the other workgroup of the CU overlaps them.  A wave cannot run
+// ahead of its own stores either: on gfx9 loads and stores share the in-order vmcnt counter, so the wait for the next tile's
+// operands is a wait for every store issued before them.  Here the waves that store never load:
+//   * kStreamWaves computing waves (the 4 x 2 blocks of 32 x 64 pairs of the tile kernel) take tile after tile (virtual
+//     workgroup indices blockIdx.x, + gridDim.x, ...: the XCD-banded order of po_tiles.h is kept, the 32 workgroups of an XCD
+//     work on 32 consecutive tiles of its range).  Operands reach them through LDS only, their vector-memory instructions are
+//     the output stores alone, and nothing ever waits for those: the stores of tile k drain under the matrix-core and
+//     float64 work of tile k + 1.
+//   * one loader wave stages the operands - a ring of two staging steps, KCH bytes of K per record and step - and the
+//     per-record terms of the NEXT tile by LDS-DMA; its vmcnt holds loads only.
+//   * hand-over by s_barrier (all kStreamWaves + 1 waves, the same sequence for every wave): barrier b_g says "step g has landed
+//     and step g - 1 has been consumed" (so the loader may refill that slot), barrier E1 after a tile's values are in the
+//     float32 tile scratch says "the scratch is complete, and the terms buffer and the last slot are free".  The scratch is read
+//     (and the stores issued) between E1 and the next tile's b_0; it is written again only after that tile's matrix-core phase.
+// LDS: ring 2 x P x 2 x (KCH / 16) x 2 KiB (64 / 64 / 48 KiB for P = 1 / 2 / 3) + 65 KiB of scratch + 6 KiB of terms.
+constexpr int kStreamWaves = 8;
+constexpr int kStreamThreads = 64 * (kStreamWaves + 1);
+template <int P> struct stream_cfg {
+    static constexpr int kch = P == 1 ? 128 : (P == 2 ? 64 : 32);      // bytes of K per record and staging step
+    static constexpr int chunks = kch / 16;                            // 16-byte K-chunks per step
+    static constexpr int step_bytes = P * 2 * chunks * kChunkBytes;
+    static constexpr int ring_bytes = 2 * step_bytes;
+    static constexpr int lds_bytes = ring_bytes + kF32TileBytes + kTermBytes;
+};
+
+template <int P, int METRIC>
+__global__ __launch_bounds__(kStreamThreads) void gram_i8_stream_kernel(po_tile_args A, const int8_t* __restrict__ planes,
+                                                                        uint32_t dpad, const double* __restrict__ rs,
+                                                                        const uint32_t* __restrict__ maxabs, long long run_above,
+                                                                        long long run_upto, uint64_t nb) {
+    if (maxabs != nullptr) {
+        const long long m = *maxabs;
+        if (m <= run_above || m > run_upto) return;
+    }
+    using cfg = stream_cfg<P>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* ring = smem;
+    float* tl = reinterpret_cast<float*>(smem + cfg::ring_bytes);
+    double* terms = reinterpret_cast<double*>(smem + cfg::ring_bytes + kF32TileBytes);   // [t0 rows | t0 cols | t1 rows | t1 cols | t2 rows | t2 cols]
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t steps = dpad / cfg::kch;                // staging steps per tile (dpad is a multiple of 128)
+    const size_t plane = (size_t)A.npad * dpad;
+    // which digit planes a tile needs (three-plane kernel: by the largest count of its two blocks of records, see above)
+    auto planes_of = [&](uint32_t ti, uint32_t tj, uint32_t& pr, uint32_t& pc) {
+        pr = P; pc = P;
+        if (P == 3 && maxabs != nullptr) {
+            const uint32_t mr = maxabs[1 + ti], mc = maxabs[1 + tj];
+            pr = mr <= 127u ? 1u : (mr <= 16383u ? 2u : 3u);
+            pc = mc <= 127u ? 1u : (mc <= 16383u ? 2u : 3u);
+        }
+    };
+
+    if (wave == kStreamWaves) {
+        // ================= the loader wave =================
+        struct tile_at { uint64_t i0, j0; uint32_t pr, pc; };
+        auto locate = [&](uint64_t w) {                                // the tile of virtual workgroup w and the planes it needs
+            uint32_t ti, tj;
+            tile_at t;
+            po_tile_coords(A, TM, w, ti, tj);
+            planes_of(ti, tj, t.pr, t.pc);
+            t.i0 = (uint64_t)ti * TM; t.j0 = (uint64_t)tj * TN;
+            return t;
+        };
+        auto stage = [&](const tile_at& t, uint32_t s, uint32_t slot) {   // step s of the tile into ring slot `slot`
+            unsigned char* dst = ring + slot * cfg::step_bytes;
+#pragma unroll
+            for (int idx = 0; idx < P * 2 * cfg::chunks * 2; ++idx) {  // one-KiB LDS-DMA instructions: [p][side][q][half]
+                const uint32_t half = idx & 1, q = (idx >> 1) % cfg::chunks, side = ((idx >> 1) / cfg::chunks) & 1, p = (idx >> 1) / (2 * cfg::chunks);
+                if (P == 3 && p >= (side ? t.pc : t.pr)) continue;     // a digit plane that is all zero for this block of records
+                const uint64_t rec = (side ? t.j0 : t.i0) + half * 64 + lane;
+                const int8_t* src = planes + p * plane + ((size_t)(s * cfg::chunks + q) * A.npad + rec) * 16;
+                po_glds16(src, dst + ((p * 2 + side) * cfg::chunks + q) * kChunkBytes + half * 1024);
+            }
+        };
+        auto stage_terms = [&](const tile_at& t) {                     // 6 x 128 doubles = six one-KiB LDS-DMA instructions
+#pragma unroll
+            for (int a = 0; a < (METRIC == PO_EUCL ? 3 : 1); ++a)
+#pragma unroll
+                for (int side = 0; side < 2; ++side)
+                    po_glds16(rs + a * A.npad + (side ? t.j0 : t.i0) + 2 * lane, reinterpret_cast<unsigned char*>(terms + a * 256 + side * 128));
+        };
+        uint32_t g = 0;                                                // global step counter: slot = g & 1
+        uint64_t w = blockIdx.x;
+        if (w >= nb) return;                                           // (uniform over the workgroup: blockIdx.x)
+        // The loader runs up to two steps ahead - the depth of the ring - also across tiles: steps 0 and 1 of the next tile are
+        // on their way while the computing waves do the float64 arithmetic of this one (barrier E0 tells the loader that the
+        // last step has been consumed; without it step 1 could only follow E1 and its latency would be exposed in every tile).
+        const uint32_t pre = steps < 2 ? steps : 2;                    // steps of a tile that are issued before its b_0
+        tile_at cur = locate(w);
+        stage(cur, 0, 0);
+        if (pre == 2) stage(cur, 1, 1);
+        stage_terms(cur);
+        for (; w < nb; w += gridDim.x) {
+            const uint64_t wn = w + gridDim.x;
+            const bool more = wn < nb;
+            const tile_at nxt = locate(more ? wn : w);
+            for (uint32_t s = 0; s < steps; ++s, ++g) {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");    // b_g: step g has landed (and the terms with step 0)
+                if (s + 1 < steps) { if (s + 1 >= pre) stage(cur, s + 1, (g + 1) & 1); }   // the slot of step g - 1 is free: refill it
+                else if (more) stage(nxt, 0, (g + 1) & 1);
+            }
+            asm volatile("s_barrier" ::: "memory");                    // E0: every step of this tile has been consumed
+            if (more && pre == 2) stage(nxt, 1, (g + 1) & 1);          // g counts the next tile's step 0 from here on
+            asm volatile("s_barrier" ::: "memory");                    // E1: the terms buffer is free
+            if (more) stage_terms(nxt);
+            cur = nxt;
+        }
+        return;
+    }
+
+    // ================= the computing waves =================
+    const uint32_t wr = wave >> 1, wc = wave & 1;          // 4 x 2 waves of 32 x 64
+    const uint32_t lr = lane & 31, lh = lane >> 5;
+    constexpr int NG = 2 * P - 1;
+    uint32_t g_step = 0;
+    for (uint64_t w = blockIdx.x; w < nb; w += gridDim.x) {
+        uint32_t ti, tj, pr, pc;
+        po_tile_coords(A, TM, w, ti, tj);
+        planes_of(ti, tj, pr, pc);
+        const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
+        v16i g[NG][2];
+#pragma unroll
+        for (int s = 0; s < NG; ++s)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) g[s][nn][e] = 0;
+        for (uint32_t s = 0; s < steps; ++s, ++g_step) {
+            po_lds_barrier();                              // b_g: this step has landed; our reads of the previous one are done
+            const unsigned char* slot = ring + (g_step & 1) * cfg::step_bytes;
+#pragma unroll
+            for (int ks = 0; ks < cfg::kch / 32; ++ks) {
+                const uint32_t q = 2 * ks + lh;            // lane halves take the two 16-byte chunks of a k-step
+                v4i a[P], b[P][2];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (P != 3 || (uint32_t)p < pr)
+                        a[p] = *reinterpret_cast<const v4i*>(slot + ((p * 2 + 0) * cfg::chunks + q) * kChunkBytes + (wr * 32 + lr) * 16);
+                    if (P != 3 || (uint32_t)p < pc) {
+#pragma unroll
+                        for (int nn = 0; nn < 2; ++nn)
+                            b[p][nn] = *reinterpret_cast<const v4i*>(slot + ((p * 2 + 1) * cfg::chunks + q) * kChunkBytes + (wc * 64 + nn * 32 + lr) * 16);
+                    }
+                }
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                    for (int pa = 0; pa < P; ++pa)
+#pragma unroll
+                        for (int pb = 0; pb < P; ++pb)
+                            if (P != 3 || ((uint32_t)pa < pr && (uint32_t)pb < pc))
+                                g[pa + pb][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pa], b[pb][nn], g[pa + pb][nn], 0, 0, 0);
             }
         }
+        po_lds_barrier();                                  // E0: the ring is free (the loader sends the next tile's second step)
+        gram_i8_values_to_tile<P, METRIC, (P == 1 ? 4 : 2)>(g, terms, wr * 32, wr * 32, wc, lr, lh, ti == tj, tl);
+        po_lds_barrier();                                  // E1: the scratch is complete
+        // (the lane index is derived again for every tile: what the store addresses need per lane would otherwise be computed
+        //  once in front of the tile loop, live across it, spilled - and reloading it would wait for the stores in flight)
+        uint32_t lane_s;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+        po_store_tile_f32<kStreamWaves>(A, po_tile_mirrors(A, ti, tj), i0, j0, wave, lane_s, tl);
     }
 }
 
@@ -276,7 +689,32 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
     if (nblocks == 0) return PO_OK;
     if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
     const size_t staging = (size_t)P * 2 * 8 * kChunkBytes;
-    const size_t shmem = (staging > (size_t)kMirrorBytes ? staging : (size_t)kMirrorBytes) + kTermBytes;
+    const size_t scratch = a.out_f32 ? (size_t)kF32TileBytes : (size_t)kMirrorBytes;      // the epilogue's LDS, over the staging area
+    const size_t shmem = (staging > scratch ? staging : scratch) + kTermBytes;
+#if !defined(PO_EXP_NO_QUAD)
+    if constexpr (P == 1) if (a.out_f32) {
+        auto k = gram_i8_quad_kernel<METRIC>;
+        PO_SHMEM(ctx, k, (size_t)kQuadLdsBytes);
+        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kQuadThreads), (size_t)kQuadLdsBytes, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto);
+        PO_CHECK_LAUNCH("gram_i8_quad_kernel");
+        return PO_OK;
+    }
+#endif
+#if !defined(PO_EXP_NO_STREAM)
+    // (three planes: five accumulator groups = 160 registers of the 168 a wave of a nine-wave workgroup may have - those tiles, the
+    //  few that hold a record of more than ~1 Mb, stay with the tile kernel and its float32 tile epilogue)
+    if constexpr (P < 3) if (a.out_f32) {
+        // one persistent workgroup per CU (a multiple of the 8 XCDs, so that a workgroup's tiles stay on its XCD's range)
+        auto k = gram_i8_stream_kernel<P, METRIC>;
+        PO_SHMEM(ctx, k, (size_t)stream_cfg<P>::lds_bytes);
+        uint64_t grid = (uint64_t)(ctx->prop.multiProcessorCount > 8 ? ctx->prop.multiProcessorCount / 8 * 8 : 8);
+        if (grid > po_round_up(nblocks, 8)) grid = po_round_up(nblocks, 8);
+        hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kStreamThreads), (size_t)stream_cfg<P>::lds_bytes, ctx->stream, a, planes, dpad, rs,
+                           maxabs, run_above, run_upto, nblocks);
+        PO_CHECK_LAUNCH("gram_i8_stream_kernel");
+        return PO_OK;
+    }
+#endif
     if (a.out_f32) {
         auto k = gram_i8_tile_kernel<P, METRIC, float>;
         PO_SHMEM(ctx, k, shmem);

@@ -194,6 +194,98 @@ __device__ __forceinline__ void po_store_pair(const po_tile_args& A, uint64_t i,
 __device__ __forceinline__ bool po_tile_mirrors(const po_tile_args& A, uint32_t ti, uint32_t tj) {
     return A.mirror != nullptr && !(A.triangular && ti == tj);
 }
+// ---- float32 output through a workgroup-wide LDS tile (round 5) ---------------------------------------
+// A float32 matrix row is half as long in bytes as a float64 one, so an epilogue that stores straight from the register layout
+// of its arithmetic leaves 128-byte crumbs (32 accumulator columns x 4 B) - one store instruction, one address computation and
+// one bounds test per element - where the float64 path writes 256 B.  Every float32 epilogue instead puts the tile's 128 x 128
+// values into LDS as float32 (tl[r * kF32TileStride + c], 65 KiB), and after ONE LDS barrier the waves write the tile and its
+// transpose as 16-byte stores, two 512-byte row pieces per instruction (tools/ubench/write_bw_f32.hip: 5.07 TB/s against 4.03
+// for the 128-byte crumbs when the rows of the matrix are only 64-byte aligned, as at N = 50 000).  Interior tiles of an aligned
+// matrix take a path without any per-lane test; everything else (edge tiles, odd leading dimensions, blocks that start inside
+// a tile) stores element by element, 256 contiguous bytes per instruction.
+// Row stride 130 floats: rows stay 8-byte aligned (the direct rows are read as two ds_read_b64 per lane) and a COLUMN of the
+// tile - what the transposed rows read - spreads over 8 bank groups (4-way conflicts on 4-byte reads, a few hundred LDS cycles
+// per tile; a stride of 132 would make that 8-way, 136 16-way).
+constexpr int kF32TileStride = 130;
+constexpr int kF32TileBytes = 128 * kF32TileStride * 4;              // 66 560 B
+
+typedef float po_f4v __attribute__((ext_vector_type(4)));
+
+// All NW waves of the workgroup call this after the values sit in `tl` and a barrier has made them visible.  ROWS = 128: the whole
+// tile; ROWS = 64: one half of it, rows i0 .. i0 + 63 (a kernel that keeps half the scratch - 33 KiB - and makes two passes: its
+// transposed rows then leave as 256-byte pieces).
+template <int NW, int ROWS = 128>
+__device__ __forceinline__ void po_store_tile_f32(const po_tile_args& A, bool mirrors, uint64_t i0, uint64_t j0, uint32_t wave,
+                                                  uint32_t lane, const float* tl) {
+    static_assert(ROWS == 128 || ROWS == 64, "whole tiles or halves");
+    float* out = static_cast<float*>(A.out);
+    const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
+#if defined(PO_EXP_NOSTORE)
+    if (A.n != 0x7fffffffffffffffull) return;                        // isolating build: everything but the global stores
+#endif
+    const bool inside = i0 >= A.row_begin && i0 + ROWS <= n_rows && j0 >= A.col_begin && j0 + 128 <= n_cols;   // uniform
+    // ---- the rows themselves: lanes 0..31 one row, lanes 32..63 the next, four columns each ----
+    if (inside && (A.ld_out & 3) == 0 && ((j0 - A.col_begin) & 3) == 0 && (reinterpret_cast<uintptr_t>(A.out) & 15) == 0) {
+        // (all LDS reads of the wave first, then its stores; the wave index is known to be below NW, so the trip count is fixed)
+        constexpr int IT = ROWS / 2 / NW;
+        const uint32_t half = lane >> 5, m = lane & 31;
+        const uint32_t r0 = 2 * (wave & (NW - 1)) + half;
+        float* dst = out + (i0 - A.row_begin + r0) * A.ld_out + (j0 - A.col_begin) + 4 * m;
+        const uint64_t step = 2 * NW * A.ld_out;
+        const float* src = tl + r0 * kF32TileStride + 4 * m;
+        po_f4v v[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const float2 a = *reinterpret_cast<const float2*>(src + it * 2 * NW * kF32TileStride);
+            const float2 b = *reinterpret_cast<const float2*>(src + it * 2 * NW * kF32TileStride + 2);
+            v[it] = po_f4v{a.x, a.y, b.x, b.y};
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) __builtin_nontemporal_store(v[it], reinterpret_cast<po_f4v*>(dst + it * step));
+    } else {
+        for (uint32_t r = wave; r < ROWS; r += NW) {
+            const uint64_t i = i0 + r;
+            if (i < A.row_begin || i >= n_rows) continue;
+            float* row = out + (i - A.row_begin) * A.ld_out;
+#pragma unroll
+            for (uint32_t c = lane; c < 128; c += 64) {
+                const uint64_t j = j0 + c;
+                if (j >= A.col_begin && j < n_cols) po_out_store(&row[j - A.col_begin], tl[r * kF32TileStride + c]);
+            }
+        }
+    }
+    if (!mirrors) return;
+    // ---- the transposed rows (columns of tl): ROWS / 4 lanes per transposed row, four entries each ----
+    float* mir = static_cast<float*>(A.mirror);
+    if (inside && (A.ld_mirror & 3) == 0 && ((i0 - A.row_begin) & 3) == 0 && (reinterpret_cast<uintptr_t>(A.mirror) & 15) == 0) {
+        constexpr int LPR = ROWS / 4, RPI = 64 / LPR, IT = 128 / RPI / NW;      // lanes per row, rows per instruction, instructions per wave
+        const uint32_t q = lane / LPR, m = lane % LPR;
+        const uint32_t c0 = RPI * (wave & (NW - 1)) + q;
+        float* dst = mir + (j0 - A.col_begin + c0) * A.ld_mirror + (i0 - A.row_begin) + 4 * m;
+        const uint64_t step = RPI * NW * A.ld_mirror;
+        const float* src = tl + 4 * m * kF32TileStride + c0;
+        po_f4v v[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const float* e = src + it * RPI * NW;
+            v[it] = po_f4v{e[0], e[kF32TileStride], e[2 * kF32TileStride], e[3 * kF32TileStride]};
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) __builtin_nontemporal_store(v[it], reinterpret_cast<po_f4v*>(dst + it * step));
+    } else {
+        for (uint32_t c = wave; c < 128; c += NW) {
+            const uint64_t j = j0 + c;
+            if (j < A.col_begin || j >= n_cols) continue;
+            float* row = mir + (j - A.col_begin) * A.ld_mirror;
+#pragma unroll
+            for (uint32_t r = lane; r < ROWS; r += 64) {
+                const uint64_t i = i0 + r;
+                if (i >= A.row_begin && i < n_rows) po_out_store(&row[i - A.row_begin], tl[r * kF32TileStride + c]);
+            }
+        }
+    }
+}
+
 // ---- register-block epilogue of the VALU tile kernels -------------------------------------------------
 // Lane (tx, ty) of an NT-lane workgroup holds v[ia][ib] for record rows i0 + ty*RPT + ia and record
 // columns j0 + 32*(ib>>1) + 2*tx + (ib&1).  The tile goes out as 16-byte stores along rows (16 lanes =

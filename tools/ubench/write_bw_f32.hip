@@ -9,7 +9,7 @@
 //   mode 5  16-byte stores, 4 rows x 256 B
 //   mode 6  16-byte stores, 1 row  x 1 KiB  (256 x 256 tiles)
 //   mode 7   8-byte stores, 4 rows x 128 B
-// argv[1] = leading dimension in elements (default 50 048: rows 128-byte aligned; 50 000 puts every other row 64 bytes off)
+// argv[2] = matrix size (default 49 920);  argv[1] = leading dimension in elements (default 50 048: rows 128-byte aligned; 50 000 puts every other row 64 bytes off)
 // build: hipcc --offload-arch=gfx950 -O3 -Iinclude -Iphyloligo_amd/csrc -o tools/ubench/write_bw_f32 tools/ubench/write_bw_f32.hip
 #include "po_tiles.h"
 #include <cstdio>
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void fill_tri_f32(po_tile_args A, float* __res
 }
 
 int main(int argc, char** argv) {
-    const uint32_t n = 49920;                      // 390 tiles of 128, 195 of 256
+    const uint32_t n = argc > 2 ? (uint32_t)strtoul(argv[2], nullptr, 10) : 49920;   // a multiple of 256 (49 920 = 390 tiles of 128; 199 936 = config 4's size, 160 GB)
     const uint64_t ld = argc > 1 ? strtoull(argv[1], nullptr, 10) : 50048;
     float* out;
     if (hipMalloc(&out, (size_t)n * ld * 4 + 4096) != hipSuccess) return 1;
