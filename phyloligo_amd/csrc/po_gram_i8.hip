@@ -117,6 +117,56 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint32_t* __rest
     }
 }
 
+// ---- which tiles a launch owns (round 5) --------------------------------------------------------------------------------
+// idx == nullptr: all `count` tiles of the block, workgroup (or virtual workgroup) w -> the XCD-banded order of po_tiles.h.
+// idx != nullptr: the `count` logical positions listed there - the tiles of ONE class (how many digit planes their two record
+// blocks need), built by classify_tiles_kernel in ascending order inside chunks of 256 positions; po_xcd_swizzle over the list
+// gives every XCD one contiguous piece of it, so the tiles an XCD works on together still share their operands.
+struct tile_list {
+    const uint32_t* idx;
+    uint64_t count;
+};
+__device__ __forceinline__ void list_tile(const po_tile_args& A, const tile_list& tl, uint64_t w, uint32_t& ti, uint32_t& tj) {
+    uint64_t L = po_xcd_swizzle(w, tl.count);
+    if (tl.idx != nullptr) L = tl.idx[L];
+    po_tile_coords_logical(A, TM, L, ti, tj);
+}
+
+__device__ __forceinline__ uint32_t plane_class(uint32_t m) { return m <= 127u ? 0u : (m <= 16383u ? 1u : 2u); }
+
+// lists[c][..] = logical positions of the block's tiles whose two record blocks need c + 1 digit planes; counts[c] their number
+// (zeroed by the caller).  A workgroup takes 256 consecutive positions and reserves its piece of every list with one atomic add.
+__global__ __launch_bounds__(256) void classify_tiles_kernel(po_tile_args A, const uint32_t* __restrict__ maxabs, uint64_t nb,
+                                                             uint32_t* __restrict__ lists, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t wave_n[3][4], base[3];
+    const uint64_t L = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t cls = 3;
+    if (L < nb) {
+        uint32_t ti, tj;
+        po_tile_coords_logical(A, TM, L, ti, tj);
+        cls = max(plane_class(maxabs[1 + ti]), plane_class(maxabs[1 + tj]));
+    }
+    uint32_t rank = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == c);
+        if (cls == c) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_n[c][wave] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const uint32_t c = threadIdx.x, total = wave_n[c][0] + wave_n[c][1] + wave_n[c][2] + wave_n[c][3];
+        base[c] = total ? atomicAdd(&counts[c], total) : 0u;
+    }
+    __syncthreads();
+    if (cls < 3) {
+        uint32_t at = base[cls] + rank;
+        for (uint32_t w = 0; w < wave; ++w) at += wave_n[cls][w];
+        lists[(size_t)cls * nb + at] = (uint32_t)L;
+    }
+}
+
 // The distance of a row record and a column record from their exact integer Gram entry G (shared by both tile kernels, so
 // that every path gives the same bits).  Per-record terms - Eucl: t0 = S/n^2, t1 = 1/n, t2 = S (exact);  SC: t0 = N.
 //   Eucl: d^2 = (t0_r + t0_c) + G * ((-2 t1_r) * t1_c): the doubling is exact, so the product of the two per-record factors is
@@ -282,7 +332,7 @@ template <int P, int METRIC, typename OUT>
 __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(po_tile_args A, const int8_t* __restrict__ planes,
                                                                                uint32_t dpad, const double* __restrict__ rs,
                                                                                const uint32_t* __restrict__ maxabs,
-                                                                               long long run_above, long long run_upto) {
+                                                                               long long run_above, long long run_upto, tile_list tiles) {
     if (maxabs != nullptr) {
         const long long m = *maxabs;
         if (m <= run_above || m > run_upto) return;
@@ -293,7 +343,7 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
     const uint32_t wr = wave >> 1, wc = wave & 1;          // 4 x 2 waves of 32 x 64
     const uint32_t lr = lane & 31, lh = lane >> 5;
     uint32_t ti, tj;
-    po_tile_coords(A, TM, blockIdx.x, ti, tj);
+    list_tile(A, tiles, blockIdx.x, ti, tj);
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
     const size_t plane = (size_t)A.npad * dpad;
     constexpr int kStepUnroll = P == 3 ? 1 : KCH / 32;
@@ -443,7 +493,7 @@ constexpr int kQuadLdsBytes = kQuadScratchBytes + kTermBytes;
 template <int METRIC>
 __global__ __launch_bounds__(kQuadThreads, 4) void gram_i8_quad_kernel(po_tile_args A, const int8_t* __restrict__ planes, uint32_t dpad,
                                                                        const double* __restrict__ rs, const uint32_t* __restrict__ maxabs,
-                                                                       long long run_above, long long run_upto) {
+                                                                       long long run_above, long long run_upto, tile_list tiles) {
     if (maxabs != nullptr) {
         const long long m = *maxabs;
         if (m <= run_above || m > run_upto) return;
@@ -454,7 +504,7 @@ __global__ __launch_bounds__(kQuadThreads, 4) void gram_i8_quad_kernel(po_tile_a
     const uint32_t wr = wave >> 1, wc = wave & 1;          // 2 x 2 waves of 64 x 64
     const uint32_t lr = lane & 31, lh = lane >> 5;
     uint32_t ti, tj;
-    po_tile_coords(A, TM, blockIdx.x, ti, tj);
+    list_tile(A, tiles, blockIdx.x, ti, tj);
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
 
     v16i g[2][1][2];                                       // [row block bi][plane sum][column block]
@@ -544,12 +594,13 @@ template <int P, int METRIC>
 __global__ __launch_bounds__(kStreamThreads) void gram_i8_stream_kernel(po_tile_args A, const int8_t* __restrict__ planes,
                                                                         uint32_t dpad, const double* __restrict__ rs,
                                                                         const uint32_t* __restrict__ maxabs, long long run_above,
-                                                                        long long run_upto, uint64_t nb) {
+                                                                        long long run_upto, tile_list tiles) {
     if (maxabs != nullptr) {
         const long long m = *maxabs;
         if (m <= run_above || m > run_upto) return;
     }
     using cfg = stream_cfg<P>;
+    const uint64_t nb = tiles.count;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* ring = smem;
     float* tl = reinterpret_cast<float*>(smem + cfg::ring_bytes);
@@ -574,7 +625,7 @@ __global__ __launch_bounds__(kStreamThreads) void gram_i8_stream_kernel(po_tile_
         auto locate = [&](uint64_t w) {                                // the tile of virtual workgroup w and the planes it needs
             uint32_t ti, tj;
             tile_at t;
-            po_tile_coords(A, TM, w, ti, tj);
+            list_tile(A, tiles, w, ti, tj);
             planes_of(ti, tj, t.pr, t.pc);
             t.i0 = (uint64_t)ti * TM; t.j0 = (uint64_t)tj * TN;
             return t;
@@ -633,7 +684,7 @@ __global__ __launch_bounds__(kStreamThreads) void gram_i8_stream_kernel(po_tile_
     uint32_t g_step = 0;
     for (uint64_t w = blockIdx.x; w < nb; w += gridDim.x) {
         uint32_t ti, tj, pr, pc;
-        po_tile_coords(A, TM, w, ti, tj);
+        list_tile(A, tiles, w, ti, tj);
         planes_of(ti, tj, pr, pc);
         const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
         v16i g[NG][2];
@@ -681,13 +732,13 @@ __global__ __launch_bounds__(kStreamThreads) void gram_i8_stream_kernel(po_tile_
     }
 }
 
+// `count` tiles: all of the block's (d_list == nullptr) or the listed ones.  The kernel runs iff run_above < *maxabs <= run_upto.
 template <int P, int METRIC>
 int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint32_t dpad, const double* rs,
-                 const uint32_t* maxabs, long long run_above, long long run_upto, uint64_t* tiles) {
-    const uint64_t nblocks = po_tile_count(a, TM);
-    if (tiles) *tiles += nblocks;
-    if (nblocks == 0) return PO_OK;
-    if (nblocks >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)nblocks); return PO_EUNSUPPORTED; }
+                 const uint32_t* maxabs, long long run_above, long long run_upto, const uint32_t* d_list, uint64_t count) {
+    if (count == 0) return PO_OK;
+    if (count >= (1ull << 31)) { po_set_error("too many tiles for one launch (%llu)", (unsigned long long)count); return PO_EUNSUPPORTED; }
+    const tile_list tl{d_list, count};
     const size_t staging = (size_t)P * 2 * 8 * kChunkBytes;
     const size_t scratch = a.out_f32 ? (size_t)kF32TileBytes : (size_t)kMirrorBytes;      // the epilogue's LDS, over the staging area
     const size_t shmem = (staging > scratch ? staging : scratch) + kTermBytes;
@@ -695,7 +746,7 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
     if constexpr (P == 1) if (a.out_f32) {
         auto k = gram_i8_quad_kernel<METRIC>;
         PO_SHMEM(ctx, k, (size_t)kQuadLdsBytes);
-        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kQuadThreads), (size_t)kQuadLdsBytes, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto);
+        hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kQuadThreads), (size_t)kQuadLdsBytes, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
         PO_CHECK_LAUNCH("gram_i8_quad_kernel");
         return PO_OK;
     }
@@ -703,14 +754,14 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
 #if !defined(PO_EXP_NO_STREAM)
     // (three planes: five accumulator groups = 160 registers of the 168 a wave of a nine-wave workgroup may have - those tiles, the
     //  few that hold a record of more than ~1 Mb, stay with the tile kernel and its float32 tile epilogue)
-    if constexpr (P < 3) if (a.out_f32) {
+    if constexpr (P == 2) if (a.out_f32) {
         // one persistent workgroup per CU (a multiple of the 8 XCDs, so that a workgroup's tiles stay on its XCD's range)
         auto k = gram_i8_stream_kernel<P, METRIC>;
         PO_SHMEM(ctx, k, (size_t)stream_cfg<P>::lds_bytes);
         uint64_t grid = (uint64_t)(ctx->prop.multiProcessorCount > 8 ? ctx->prop.multiProcessorCount / 8 * 8 : 8);
-        if (grid > po_round_up(nblocks, 8)) grid = po_round_up(nblocks, 8);
+        if (grid > po_round_up(count, 8)) grid = po_round_up(count, 8);
         hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kStreamThreads), (size_t)stream_cfg<P>::lds_bytes, ctx->stream, a, planes, dpad, rs,
-                           maxabs, run_above, run_upto, nblocks);
+                           maxabs, run_above, run_upto, tl);
         PO_CHECK_LAUNCH("gram_i8_stream_kernel");
         return PO_OK;
     }
@@ -718,11 +769,11 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
     if (a.out_f32) {
         auto k = gram_i8_tile_kernel<P, METRIC, float>;
         PO_SHMEM(ctx, k, shmem);
-        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto);
+        hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
     } else {
         auto k = gram_i8_tile_kernel<P, METRIC, double>;
         PO_SHMEM(ctx, k, shmem);
-        hipLaunchKernelGGL(k, dim3((uint32_t)nblocks), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto);
+        hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
     }
     PO_CHECK_LAUNCH("gram_i8_tile_kernel");
     return PO_OK;
@@ -774,17 +825,73 @@ int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_vals, const uint64_t* 
     return PO_OK;
 }
 
-// Eucl: the one-, two- and three-plane kernels (max <= 127, <= 16 383, <= limit) are all launched and one of them runs;
+// The largest counts on the host: [whole matrix, every block of 128 records].  Waits for the stream (16 bytes + 4 per block).
+int po_gram_i8_block_maxima(po_ctx* ctx, const void* ws, uint64_t npad, uint32_t dim, const uint32_t** h_max) {
+    const ws_view v = view(const_cast<void*>(ws), npad, dim);
+    const size_t words = 1 + npad / 128;
+    if (ctx->h_blockmax_cap < words) {
+        if (ctx->h_blockmax) (void)hipHostFree(ctx->h_blockmax);
+        ctx->h_blockmax = nullptr; ctx->h_blockmax_cap = 0;
+        const size_t cap = words + words / 2 + 64;
+        PO_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_blockmax), cap * sizeof(uint32_t), hipHostMallocDefault));
+        ctx->h_blockmax_cap = cap;
+    }
+    PO_HIP(hipMemcpyAsync(ctx->h_blockmax, v.maxabs, words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PO_HIP(hipStreamSynchronize(ctx->stream));
+    *h_max = ctx->h_blockmax;
+    return PO_OK;
+}
+
+// Eucl.  Without the host's copy of the largest counts (h_max == NULL: small matrices, where a host synchronisation would cost more
+// than workgroups that leave at once): the one-, two- and three-plane kernels (max <= 127, <= 16 383, <= limit) are all launched over
+// all tiles and one of them runs.  With it (round 5): a tile needs as many digit planes as the larger of its two record blocks'
+// largest counts - in a real assembly a handful of Mb-scale contigs need the third digit, most blocks one or two - so the tiles
+// are dealt to the kernels by class: the host counts the tiles of every class from the block maxima (products of block counts),
+// classify_tiles_kernel writes their positions, and every kernel is launched over exactly its own list.  One class only (every
+// BASELINE config): no lists, one launch.  Results do not depend on the class a tile runs in (the Gram entries are exact).
 // SC: two planes, unconditionally.
-int po_launch_gram_i8_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const void* ws, uint64_t* tiles) {
+int po_launch_gram_i8_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const void* ws, const uint32_t* h_max, uint64_t* tiles) {
     const ws_view v = view(const_cast<void*>(ws), a.npad, a.dim);
-    if (metric == PO_SC) return launch_tiles<2, PO_SC>(ctx, a, v.planes, v.dpad, v.rs, nullptr, 0, 0, tiles);
+    const uint64_t nb = po_tile_count(a, TM);
+    if (tiles) *tiles += nb;
+    if (nb == 0) return PO_OK;
+    constexpr long long kAlways = 0x7fffffffffffffffll;
+    if (metric == PO_SC) return launch_tiles<2, PO_SC>(ctx, a, v.planes, v.dpad, v.rs, nullptr, -1, kAlways, nullptr, nb);
     if (metric != PO_EUCL) { po_set_error("po_launch_gram_i8_tiles: metric %d is not a Gram-form metric", metric); return PO_EINVAL; }
-    int rc = launch_tiles<1, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, -1, 127, tiles);
-    if (rc) return rc;
     const uint32_t limit = po_gram_i8_value_limit(a.dim);
-    if (limit > 127) rc = launch_tiles<2, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, 127, limit < 16383u ? limit : 16383u, nullptr);
+    if (h_max == nullptr) {
+        int rc = launch_tiles<1, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, -1, 127, nullptr, nb);
+        if (rc) return rc;
+        if (limit > 127) rc = launch_tiles<2, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, 127, limit < 16383u ? limit : 16383u, nullptr, nb);
+        if (rc) return rc;
+        if (limit > 16383) rc = launch_tiles<3, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, 16383, limit, nullptr, nb);
+        return rc;
+    }
+    if (h_max[0] > limit) return PO_OK;                   // the float64 Gram kernel owns the matrix
+    // tiles of class <= c: (row blocks of class <= c) x (column blocks of class <= c); in a triangular block m (m + 1) / 2
+    auto cls = [&](uint64_t blk) { const uint32_t m = h_max[1 + blk]; return m <= 127u ? 0 : (m <= 16383u ? 1 : 2); };
+    const uint64_t r0 = a.row_begin / TM, r1 = (a.row_end + TM - 1) / TM, c0 = a.col_begin / TN, c1 = (a.col_end + TN - 1) / TN;
+    uint64_t rows_le[3] = {0, 0, 0}, cols_le[3] = {0, 0, 0}, le[3];
+    for (uint64_t b = r0; b < r1; ++b) for (int c = cls(b); c < 3; ++c) ++rows_le[c];
+    for (uint64_t b = c0; b < c1; ++b) for (int c = cls(b); c < 3; ++c) ++cols_le[c];
+    for (int c = 0; c < 3; ++c) le[c] = a.triangular ? rows_le[c] * (rows_le[c] + 1) / 2 : rows_le[c] * cols_le[c];
+    const uint64_t count[3] = {le[0], le[1] - le[0], le[2] - le[1]};
+    if (le[2] != nb) { po_set_error("po_launch_gram_i8_tiles: %llu tiles classified, %llu in the block", (unsigned long long)le[2], (unsigned long long)nb); return PO_EINVAL; }
+    const uint32_t* lists = nullptr;
+    if ((count[0] != 0) + (count[1] != 0) + (count[2] != 0) > 1) {
+        if (nb >= (1ull << 32)) { po_set_error("too many tiles for a tile list (%llu)", (unsigned long long)nb); return PO_EUNSUPPORTED; }
+        int rc = po_buf_reserve(ctx, &ctx->ws_tilelist, 3 * nb * sizeof(uint32_t) + 64);
+        if (rc) return rc;
+        uint32_t* counters = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ctx->ws_tilelist.p) + 3 * nb * sizeof(uint32_t));
+        PO_HIP(hipMemsetAsync(counters, 0, 16, ctx->stream));
+        hipLaunchKernelGGL(classify_tiles_kernel, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, ctx->stream, a, v.maxabs, nb,
+                           static_cast<uint32_t*>(ctx->ws_tilelist.p), counters);
+        PO_CHECK_LAUNCH("classify_tiles_kernel");
+        lists = static_cast<const uint32_t*>(ctx->ws_tilelist.p);
+    }
+    int rc = launch_tiles<1, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, -1, kAlways, lists, count[0]);
     if (rc) return rc;
-    if (limit > 16383) rc = launch_tiles<3, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, 16383, limit, nullptr);
-    return rc;
+    rc = launch_tiles<2, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, -1, kAlways, lists ? lists + nb : nullptr, count[1]);
+    if (rc) return rc;
+    return launch_tiles<3, PO_EUCL>(ctx, a, v.planes, v.dpad, v.rs, v.maxabs, -1, kAlways, lists ? lists + 2 * nb : nullptr, count[2]);
 }

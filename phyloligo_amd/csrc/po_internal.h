@@ -69,6 +69,9 @@ struct po_ctx {
     uint64_t fasta_len = 0, fasta_records = 0, fasta_seq_bytes = 0;
     uint32_t fold_dim = 0, fold_gran = 0, fold_dim_f = 0, fold_dbl_at = 0;
     uint32_t* h_flag = nullptr;        // pinned host word for the fold decision
+    uint32_t* h_blockmax = nullptr;    // pinned host copy of the int8 Gram path's largest counts (whole matrix, then per 128-record block)
+    size_t h_blockmax_cap = 0;         // in words
+    po_buf ws_tilelist;                // per-class tile lists of the int8 Gram path (po_gram_i8.hip)
     void* h_stage[2] = {nullptr, nullptr};   // pinned staging buffers of the host-pointer entry points (device -> host rows)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -182,7 +185,12 @@ bool po_gram_i8_sc_supported(uint32_t dim);          // Spearman's doubled centr
 // digit planes + per-record terms from uint32 counts (Eucl) or int32 doubled centred ranks (SC, signed_values)
 int po_launch_gram_i8_prep(po_ctx* ctx, const uint32_t* d_vals, const uint64_t* d_totals, bool signed_values, uint64_t n,
                            uint32_t dim, uint64_t npad, void* ws, const uint32_t** maxabs_out);
-int po_launch_gram_i8_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const void* ws, uint64_t* tiles);
+// h_max (may be NULL): host copy of the largest counts, from po_gram_i8_block_maxima - the launcher then deals the tiles to the
+// one- / two- / three-plane kernels by the classes of their two record blocks (exact grids, nothing launched to exit at once);
+// NULL: every candidate kernel is launched over all tiles and the device-side maximum decides which one runs
+int po_launch_gram_i8_tiles(po_ctx* ctx, int metric, const po_tile_args& a, const void* ws, const uint32_t* h_max, uint64_t* tiles);
+// waits for the stream: *h_max = [largest count of the matrix, largest count of every block of 128 records]
+int po_gram_i8_block_maxima(po_ctx* ctx, const void* ws, uint64_t npad, uint32_t dim, const uint32_t** h_max);
 int po_launch_gram_norms(po_ctx* ctx, const double* ft, uint32_t dim, uint64_t npad, double* rowstat, const uint32_t* skip_flag,
                          uint32_t skip_upto);
 // i8flag (may be NULL): device word holding the largest count; the float64 kernel leaves the matrix to the

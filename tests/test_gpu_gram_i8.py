@@ -190,3 +190,53 @@ def test_frequency_input_recovers_the_integer_profiles(ctx):
         got, st = ctx.pairwise_freq(bumped, metric, want_stats=True)
         assert st["kernel_id"] == general
         np.testing.assert_allclose(got, ctx.pairwise_freq(freq, metric), rtol=1e-9, atol=1e-12)
+
+
+def test_eucl_tiles_dealt_to_the_plane_kernels_by_class(ctx):
+    """Round 5: from 8 192 records on the host reads the largest count of every 128-record block and deals the tiles to the one- /
+    two- / three-plane kernels by class (device-built tile lists, exact grids).  9 000 records: most blocks with counts <= 60, four
+    blocks with a record of counts to 5 000, one block with a record of counts to 1 000 000 - so all three classes are present, in
+    the triangular matrix, in a row range and in rectangular blocks with mirrors.  Every entry written (the buffers start as NaN),
+    exactly symmetric, duplicates exactly 0, float32 = the rounded float64 values, the float64 Gram kernel and the oracle agree."""
+    import torch
+    rng = np.random.default_rng(2025)
+    n, dim = 9000, 256
+    counts = rng.integers(0, 60, size=(n, dim), dtype=np.uint32)
+    for r in (700, 2100, 2101, 5000, 8990):
+        counts[r] = rng.integers(0, 5000, size=dim)
+    counts[3333] = rng.integers(0, 1_000_000, size=dim)
+    counts[4000] = counts[10]                                   # duplicates across classes of blocks
+    counts[8991] = counts[700]
+    counts[20] = 0
+    totals = counts.sum(1).astype(np.uint64)
+    dc, dt = torch.from_numpy(counts.view(np.int32)).cuda(), torch.from_numpy(totals.view(np.int64)).cuda()
+    out = torch.full((n, n), float("nan"), dtype=torch.float64, device="cuda")
+    _, st = ctx.pairwise(dc, dt, "Eucl", out=out, want_stats=True)
+    assert st["kernel_id"] == I8 and st["tiles"] == 71 * 72 // 2
+    assert not bool(torch.isnan(out).any())
+    assert bool(torch.equal(out, out.T)) and bool((torch.diagonal(out) == 0).all())
+    assert float(out[10, 4000]) == 0.0 and float(out[8991, 700]) == 0.0
+    out32 = torch.full((n, n), float("nan"), dtype=torch.float32, device="cuda")
+    ctx.pairwise(dc, dt, "Eucl", out=out32, dtype="float32")
+    assert bool(torch.equal(out32, out.to(torch.float32)))
+    general = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    ctx.pairwise(dc, dt, "Eucl", out=general, table_path=False)
+    assert bool(torch.allclose(out, general, rtol=1e-9, atol=1e-13))
+    rows = [0, 20, 700, 2100, 3333, 4000, 8999]
+    freq = oracle.counts_to_frequencies(counts.astype(np.int64), totals.astype(np.int64))
+    want = oracle.pairwise_rows(freq, "Eucl", rows)
+    np.testing.assert_allclose(out[rows].cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    # a row range (a rectangular block without a mirror) and two rectangular blocks with mirrors, float64 and float32
+    sub = torch.full((1500, n), float("nan"), dtype=torch.float64, device="cuda")
+    ctx.pairwise(dc, dt, "Eucl", out=sub, row_begin=2048, row_end=3548)
+    assert bool(torch.equal(sub, out[2048:3548]))
+    for dtype, full in (("float64", out), ("float32", out32)):
+        td = torch.float64 if dtype == "float64" else torch.float32
+        blocks = []
+        for (r0, r1), (c0, c1) in (((0, 2560), (2560, 9000)), ((3200, 3456), (640, 2200))):
+            blocks.append({"rows": (r0, r1), "cols": (c0, c1), "out": torch.full((r1 - r0, c1 - c0), float("nan"), dtype=td, device="cuda"),
+                           "mirror": torch.full((c1 - c0, r1 - r0), float("nan"), dtype=td, device="cuda")})
+        ctx.pairwise_blocks(dc, dt, "Eucl", blocks, dtype=dtype)
+        for b in blocks:
+            (r0, r1), (c0, c1) = b["rows"], b["cols"]
+            assert bool(torch.equal(b["out"], full[r0:r1, c0:c1])) and bool(torch.equal(b["mirror"], full[c0:c1, r0:r1]))
