@@ -149,7 +149,8 @@ __global__ __launch_bounds__(kThreads, 2) void bc_sad_tile_kernel(po_tile_args A
             v[ia][ib] = (i == j) ? 0.0 : ((double)acc[ia][ib] * inv_n) / (wi[ia] + wj);
         }
     }
-    po_store_block<OUT, 8, kThreads>(A, ti, tj, i0, j0, tx, ty, v, reinterpret_cast<double*>(smem));
+    if constexpr (sizeof(OUT) == 4) po_store_block_f32<8, kThreads>(A, ti, tj, i0, j0, tx, ty, v, reinterpret_cast<float*>(smem));
+    else po_store_block<OUT, 8, kThreads>(A, ti, tj, i0, j0, tx, ty, v, reinterpret_cast<double*>(smem));
 }
 
 }  // namespace

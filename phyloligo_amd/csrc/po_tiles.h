@@ -347,6 +347,31 @@ __device__ __forceinline__ void po_store_block_part(const po_tile_args& A, bool 
     }
 }
 
+// float32 output of the same register block (round 5): instead of 8-byte stores of two columns per lane - 128-byte row pieces -
+// the values go through the float32 scratch of po_store_tile_f32, half a tile at a time (rows 0..63 are held by the lanes with
+// ty * RPT < 64, rows 64..127 by the others; 33 KiB, the size of the mirror scratch above), and leave as 16-byte stores of
+// 512-byte (tile) and 256-byte (transposed tile) row pieces.
+template <int RPT, int NT>
+__device__ __forceinline__ void po_store_block_f32(const po_tile_args& A, uint32_t ti, uint32_t tj, uint64_t i0, uint64_t j0,
+                                                   uint32_t tx, uint32_t ty, const double (&v)[RPT][8], float* tl) {
+    const bool mirrors = po_tile_mirrors(A, ti, tj);                 // uniform over the workgroup
+    const uint32_t t = ty * 16 + tx, lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+        po_lds_barrier();                                             // whoever read the scratch before is done
+        if ((ty * RPT) / 64 == h) {
+            float* row = tl + (ty * RPT - 64 * h) * kF32TileStride + 2 * tx;
+#pragma unroll
+            for (int ia = 0; ia < RPT; ++ia)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float2*>(row + ia * kF32TileStride + 32 * q) = make_float2((float)v[ia][2 * q], (float)v[ia][2 * q + 1]);
+        }
+        po_lds_barrier();
+        po_store_tile_f32<NT / 64, 64>(A, mirrors, i0 + 64 * h, j0, wave, lane, tl);
+    }
+}
+
 template <typename OUT, int RPT, int NT>
 __device__ __forceinline__ void po_store_block(const po_tile_args& A, uint32_t ti, uint32_t tj, uint64_t i0, uint64_t j0,
                                                uint32_t tx, uint32_t ty, const double (&v)[RPT][8], double* lds) {
