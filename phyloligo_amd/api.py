@@ -393,27 +393,45 @@ class _LineTitles:
         return list(self) == list(other)
 
 
-def fasta_index_dev(ctx, path):
+def fasta_index_dev(ctx, path, phases=None):
     """FASTA file -> (seq uint8 CUDA tensor, offsets int64 CUDA tensor [n+1], titles): the file bytes go to HBM as they
     are and are parsed there (po_fasta_scan_dev / po_fasta_extract_dev).  Raises PhyloligoError(PO_EUNSUPPORTED) for the
-    one construct left to the host parser (tabs on sequence lines): callers fall back to fasta_index()."""
+    one construct left to the host parser (tabs on sequence lines): callers fall back to fasta_index().
+    phases: a dict that receives the wall time of every step in ms (the device is synchronised between steps only then)."""
     import os
+    import time
     import torch
     lib = _lib.load()
     size = os.path.getsize(path)
     dev = torch.device("cuda", ctx.device)
+
+    t_last = [time.perf_counter()]
+
+    def mark(name):
+        if phases is not None:
+            torch.cuda.synchronize(dev)
+            now = time.perf_counter()
+            phases[name] = phases.get(name, 0.0) + (now - t_last[0]) * 1e3
+            t_last[0] = now
+
     buf = np.empty(size, dtype=np.uint8)
     check(lib.po_file_read(str(path).encode(), _np_ptr(buf), size))
+    mark("file_read_ms")
     raw = torch.from_numpy(buf).to(dev)
+    mark("file_h2d_ms")
     nrec, nbytes = ctypes.c_uint64(), ctypes.c_uint64()
     ctx._use_torch_stream()
     check(lib.po_fasta_scan_dev(ctx._h, raw.data_ptr(), size, ctypes.byref(nrec), ctypes.byref(nbytes)))
+    mark("fasta_scan_ms")
     seq = torch.empty(((nbytes.value + 15) // 16 * 16 or 16,), dtype=torch.uint8, device=dev)
     offsets = torch.zeros((nrec.value + 1,), dtype=torch.int64, device=dev)
     tb = torch.empty((max(1, nrec.value),), dtype=torch.int64, device=dev)
     te = torch.empty((max(1, nrec.value),), dtype=torch.int64, device=dev)
+    mark("device_alloc_ms")
     check(lib.po_fasta_extract_dev(ctx._h, raw.data_ptr(), size, seq.data_ptr(), offsets.data_ptr(), tb.data_ptr(), te.data_ptr()))
+    mark("fasta_extract_ms")
     titles = _LineTitles(buf, tb[:nrec.value].cpu().numpy(), te[:nrec.value].cpu().numpy())
+    mark("title_spans_d2h_ms")
     return seq[:nbytes.value], offsets, titles
 
 

@@ -19,6 +19,8 @@ from ._lib import METRICS, STRANDS
 
 _ctx = None
 LAST_STAGE2 = None       # PoStats of the first stage-2 call of the last compute_distances() (what --json-stats reports)
+LAST_INGEST = None       # phase -> ms of the last compute_frequencies() when INGEST_PHASES is set (--json-stats, bench.py)
+INGEST_PHASES = False    # time every step of compute_frequencies() (synchronises the device between steps)
 
 
 def _timing(text):
@@ -62,14 +64,14 @@ def read_fasta(genome):
         del data
 
 
-def read_fasta_device(genome):
+def read_fasta_device(genome, phases=None):
     """The same records through the on-device parser: (seq CUDA uint8, offsets CUDA int64[n+1], titles), or None when
     the file has the one construct that parser leaves to the host (tabs on sequence lines) or is empty."""
     from ._lib import PhyloligoError, PO_EUNSUPPORTED
     if os.path.getsize(genome) == 0 or "torch" not in sys.modules:      # the device buffers of this path are torch tensors
         return None
     try:
-        return api.fasta_index_dev(_context(), genome)
+        return api.fasta_index_dev(_context(), genome, phases)
     except PhyloligoError as exc:
         if exc.status == PO_EUNSUPPORTED:
             return None
@@ -79,6 +81,7 @@ def read_fasta_device(genome):
 def compute_frequencies(mthdrun, large, genome, pattern, strand, distchunksize=250, threads_max=4, workdir="."):
     """phyloligo.py:980-997.  Returns (frequencies, freq_name); freq_name is always None here
     (no on-disk frequency container: the count matrix lives in HBM / host memory)."""
+    global LAST_INGEST
     if mthdrun not in ("joblib", "scoop", "hip"):
         print("Method {} is unknown".format(mthdrun), file=sys.stderr)      # :995, no exit
         return None, None
@@ -86,20 +89,48 @@ def compute_frequencies(mthdrun, large, genome, pattern, strand, distchunksize=2
         print("Error, strand parameter of selectd_strand() should be choose from {'both', 'minus', 'plus'}",
               file=sys.stderr)
         sys.exit(1)
+    phases = {} if INGEST_PHASES else None
+    t_last = [time.perf_counter()]
+
+    def mark(name, sync=None):
+        if phases is not None:
+            if sync is not None:
+                sync()
+            now = time.perf_counter()
+            phases[name] = phases.get(name, 0.0) + (now - t_last[0]) * 1e3
+            t_last[0] = now
+
     ctx = _context()
-    ingest = read_fasta_device(genome)
+    mark("context_ms")
+    ingest = read_fasta_device(genome, phases)
+    mark("fasta_index_other_ms")
+    if phases is not None:                 # (the steps inside were timed there: only what is left of the call counts here)
+        phases["fasta_index_other_ms"] -= sum(phases.get(k, 0.0) for k in ("file_read_ms", "file_h2d_ms", "fasta_scan_ms", "device_alloc_ms",
+                                                                             "fasta_extract_ms", "title_spans_d2h_ms"))
     if ingest is not None:
         # file bytes -> HBM -> records -> profiles -> frequencies without the sequence ever being walked on the host
+        import torch
         d_seq, d_off, titles = ingest
         d_counts, d_totals = ctx.count_profiles(d_seq, d_off, pattern, strand)
-        freq = ctx.frequencies(d_counts, d_totals).cpu().numpy()
+        mark("stage1_ms", torch.cuda.synchronize)
+        d_freq = ctx.frequencies(d_counts, d_totals)
+        mark("count2freq_ms", torch.cuda.synchronize)
+        freq = d_freq.cpu().numpy()
+        mark("frequencies_d2h_ms")
         counts = d_counts.cpu().numpy().view(np.uint32)
         totals = d_totals.cpu().numpy().view(np.uint64)
+        mark("counts_d2h_ms")
     else:
         seq, offsets, titles = read_fasta(genome)
+        mark("host_parse_ms")
         counts, totals = ctx.count_profiles(seq, offsets, pattern, strand)
+        mark("stage1_host_pointers_ms")
         freq = ctx.frequencies(counts, totals)
-    return ProfileMatrix(freq, counts, totals, titles), None
+        mark("count2freq_host_pointers_ms")
+    result = ProfileMatrix(freq, counts, totals, titles)
+    mark("wrap_ms")
+    LAST_INGEST = phases
+    return result, None
 
 
 def _reserve_file(fd, size):
@@ -530,6 +561,8 @@ def main(argv=None):
     if not os.path.isdir(params.workdir):
         os.makedirs(params.workdir)
     print("Computing frequencies")
+    global INGEST_PHASES
+    INGEST_PHASES = bool(params.json_stats)              # the phase times of the ingest go into the JSON record
     frequencies, freq_name = compute_frequencies(params.mthdrun, params.large, params.genome, params.pattern,
                                                  params.strand, params.distchunksize, params.threads_max,
                                                  params.workdir)
@@ -569,7 +602,8 @@ def _write_json_stats(params, frequencies, freq_s, dist_s, write_s, total_s, gpu
              "strand": params.strand, "metric": params.dist, "large": params.large, "pairs": n * (n - 1) // 2,
              "seconds": {"frequencies": freq_s, "distances" + ("_and_container" if params.large in ("memmap", "h5py") else ""): dist_s,
                          "writing": write_s, "total": total_s},
-             "stage2_first_call": LAST_STAGE2}
+             "stage2_first_call": LAST_STAGE2,
+             "ingest_phases_ms": None if LAST_INGEST is None else {k: round(v, 3) for k, v in LAST_INGEST.items()}}
     with open(params.json_stats, "w") as fh:
         json.dump(stats, fh, indent=1)
         fh.write("\n")

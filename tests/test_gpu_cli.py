@@ -348,6 +348,10 @@ def test_json_stats(fasta, tmp_path, capsys):
     assert st["library"].startswith("phyloligo_amd") and len(st["device"]) > 0
     assert set(st["seconds"]) == {"frequencies", "distances", "writing", "total"} and st["seconds"]["total"] > 0
     assert st["stage2_first_call"]["kernel_id"] in (1, 6) and st["stage2_first_call"]["rows"] == [0, 48]
+    # round 5: every step of the ingest with its own time (device parser when torch is loaded, host parser otherwise)
+    ph = st["ingest_phases_ms"]
+    assert ("file_read_ms" in ph and "stage1_ms" in ph and "frequencies_d2h_ms" in ph) or ("host_parse_ms" in ph and "stage1_host_pointers_ms" in ph)
+    assert all(v >= 0 for v in ph.values()) and sum(ph.values()) <= st["seconds"]["frequencies"] * 1e3 * 1.05 + 1.0
     np.testing.assert_allclose(np.loadtxt(out, delimiter="\t"), g["JSD_1111_both"], rtol=1e-6, atol=1e-12)
 
 

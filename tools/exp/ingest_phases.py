@@ -51,4 +51,18 @@ for rnd in range(3):
     t0 = time.perf_counter()
     freq, _ = P.compute_frequencies("hip", "memmap", fa, "1111", "both", 250, 4, tmp)
     print("compute_frequencies() call %d: %.1f ms" % (rnd, (time.perf_counter() - t0) * 1e3), flush=True)
+# the bench's own sequence: a SECOND context (phyloligo.py keeps its own), created on first use
+import importlib
+P._ctx = None
+t0 = time.perf_counter(); c2 = pa.Context(0); t1 = time.perf_counter()
+print("second Context(): %.1f ms" % ((t1 - t0) * 1e3), flush=True)
+c2.close()
+with open(fa, "wb") as fh:
+    fh.write(synthetic.fasta_bytes(seq, off))
+P._ctx = None
+torch.cuda.empty_cache()
+for rnd in range(3):
+    t0 = time.perf_counter()
+    freq, _ = P.compute_frequencies("hip", "memmap", fa, "1111", "both", 250, 4, tmp)
+    print("fresh module context, empty torch cache: compute_frequencies() call %d: %.1f ms" % (rnd, (time.perf_counter() - t0) * 1e3), flush=True)
 os.remove(fa)
