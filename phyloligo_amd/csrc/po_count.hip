@@ -252,6 +252,116 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
     if (blockIdx.x == 0 && t == 0) chunk_start[n] = *total;
 }
 
+// ---- the same in ONE launch (round 5) --------------------------------------------------------------------------------------
+// Three dependent launches of a few microseconds of work each cost ~15 us of dispatch and drain around a 42 us counting kernel.
+// Here a workgroup takes a ticket (its position in the scan; tickets are handed out in the order workgroups START, so a workgroup
+// only ever waits for workgroups that are already running - no assumption about how many fit on the chip), publishes the number
+// of chunks of its 1024 records and the largest record among them at once, then waits for the aggregates of all tickets before
+// its own and adds them up (its lanes poll 256 predecessors at a time).  Aggregates carry the call's epoch in their upper half:
+// the state buffer belongs to this kernel alone and entries of earlier calls can never be mistaken for this call's, so nothing
+// is cleared between calls; the workgroup with the last ticket - which has seen every aggregate - writes the grand total and the
+// largest record and hands the ticket counter back at zero.  The word totals of the records are zeroed on the way (one memset
+// less).  Up to kOnePassBlocks workgroups (4 M records); beyond that the three launches above.
+constexpr uint32_t kOnePassBlocks = 4096;
+__global__ __launch_bounds__(256) void scan_chunks_kernel(const uint64_t* __restrict__ begins, const uint64_t* __restrict__ ends, uint32_t n,
+                                                          uint32_t nb, unsigned long long* __restrict__ agg, unsigned long long* __restrict__ big,
+                                                          uint32_t* __restrict__ ticket, uint32_t* __restrict__ empty_tag, uint32_t epoch,
+                                                          uint32_t* __restrict__ chunk_start,
+                                                          uint32_t* __restrict__ rec_of_chunk, uint32_t* __restrict__ max_chunks,
+                                                          unsigned long long* __restrict__ totals) {
+    __shared__ uint32_t part[256], wmax[4], my_ticket, prefix_s, max_s;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) my_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t blk = my_ticket;
+    const uint32_t base = blk * 1024 + t * 4;
+    uint32_t c[4], s = 0, m = 0;
+    for (uint32_t e = 0; e < 4; ++e) {
+        c[e] = (base + e < n) ? chunks_of(begins, ends, base + e) : 0u;
+        s += c[e];
+        m = max(m, c[e]);
+        if (base + e < n) {
+            totals[base + e] = 0ull;
+            if (c[e] == 0u) *empty_tag = epoch;                     // a record without a chunk: nobody writes its row (zero_rows_kernel)
+        }
+    }
+    part[t] = s;
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_down(m, o, 64));
+    if ((t & 63) == 0) wmax[t >> 6] = m;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t u = (t >= d) ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += u;
+        __syncthreads();
+    }
+    const unsigned long long tag = (unsigned long long)epoch << 32;
+    if (t == 0) {
+        const uint32_t bm = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        __hip_atomic_store(&big[blk], tag | bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&agg[blk], tag | part[255], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        prefix_s = 0; max_s = bm;
+    }
+    __syncthreads();
+    // the aggregates of every ticket before this one (each lane polls its own predecessors)
+    uint32_t pre = 0, pm = 0;
+    for (uint32_t i = t; i < blk; i += 256) {
+        unsigned long long v;
+        do { v = __hip_atomic_load(&agg[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 32) != epoch);
+        pre += (uint32_t)v;
+        if (blk == nb - 1) pm = max(pm, (uint32_t)__hip_atomic_load(&big[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    for (int o = 32; o > 0; o >>= 1) { pre += __shfl_down(pre, o, 64); pm = max(pm, (uint32_t)__shfl_down(pm, o, 64)); }
+    if ((t & 63) == 0) { atomicAdd(&prefix_s, pre); atomicMax(&max_s, pm); }
+    __syncthreads();
+    uint32_t run = prefix_s + part[t] - s;
+    // the inverse map chunk -> record (see scan_apply_kernel)
+    uint32_t first[4];
+    bool wide = false;
+    for (uint32_t e = 0; e < 4; ++e) {
+        if (base + e < n) chunk_start[base + e] = run;
+        first[e] = run;
+        if (c[e] <= 32u) { for (uint32_t q = 0; q < c[e]; ++q) rec_of_chunk[run + q] = base + e; }
+        else wide = true;
+        run += c[e];
+    }
+    unsigned long long todo = __ballot(wide);
+    const uint32_t lane = t & 63;
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t cnt = (uint32_t)__shfl((int)c[e], src, 64), at = (uint32_t)__shfl((int)first[e], src, 64);
+            const uint32_t rec = (uint32_t)__shfl((int)(base + e), src, 64);
+            if (cnt > 32u && cnt <= kWaveFillChunks) for (uint32_t q = lane; q < cnt; q += 64) rec_of_chunk[at + q] = rec;
+        }
+    }
+    if (blk == nb - 1 && t == 0) {
+        chunk_start[n] = prefix_s + part[255];
+        *max_chunks = max_s;
+        *ticket = 0u;                                               // every ticket of this call has been taken
+    }
+}
+
+// Rows that count_kernel ADDS into must be zero first: those of records whose chunks do not all sit in one workgroup of that
+// kernel (the others are written whole, with plain stores) and those of records without a chunk (nobody writes them).  With
+// word spaces beyond the LDS histogram every row is added into.  A fixed grid walks the matrix 16 bytes per lane; an assembly of
+// short contigs (C2: every record one chunk) has nothing to zero and the kernel leaves at its first test - the 51 MB memset of
+// rounds 1 - 4 cost 12 us of a 42 us counting kernel there.
+__global__ __launch_bounds__(256) void zero_rows_kernel(const uint32_t* __restrict__ chunk_start, const uint32_t* __restrict__ max_chunks,
+                                                        const uint32_t* __restrict__ empty_tag, uint32_t epoch, uint32_t n, uint32_t dim,
+                                                        uint32_t wpb, uint32_t* __restrict__ counts) {
+    if (*max_chunks <= 1u && *empty_tag != epoch) return;          // every record is one chunk: every row is written whole
+    const uint64_t quads_per_row = dim / 4;                        // dim is a power of 4 >= 4
+    const uint64_t total = (uint64_t)n * quads_per_row;
+    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (uint64_t)gridDim.x * 256) {
+        const uint32_t rec = (uint32_t)(q / quads_per_row);
+        const uint32_t f = chunk_start[rec], c = chunk_start[rec + 1] - f;
+        const bool whole = *max_chunks > 1u ? (c >= 1u && (f % wpb) + c <= wpb) : c == 1u;
+        if (!whole) reinterpret_cast<uint4*>(counts)[q] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 // The record of chunk c when some record is longer than kWaveFillChunks chunks and the scan left its entries of rec_of_chunk
 // unwritten (whatever the workspace held): an entry is right iff c lies in that record's chunk range; if not, binary search
 // through chunk_start (the largest record whose first chunk is <= c; ~20 dependent loads, long records only).
@@ -832,17 +942,40 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     uint32_t* d_max_chunks = blockmax + nb;
     uint32_t* rec_of_chunk = d_max_chunks + 1;                     // [max_chunks]: chunk -> record, written by scan_apply_kernel
 
-    // rows of single-chunk records are written whole by their wave; only multi-chunk records (rare:
-    // longer than 2 kb) accumulate with atomics and need zeros first.  Zero everything: 1 memset.
-    PO_HIP(hipMemsetAsync(d_counts, 0, n_seqs * (uint64_t)pat.dim * sizeof(uint32_t), ctx->stream));
-    PO_HIP(hipMemsetAsync(d_totals, 0, n_seqs * sizeof(uint64_t), ctx->stream));
-
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_begins, d_ends, (uint32_t)n_seqs, blocksum, blockmax);
-    PO_CHECK_LAUNCH("scan_block_sums_kernel");
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, blocksum, nb, total, blockmax, d_max_chunks);
-    PO_CHECK_LAUNCH("scan_sums_kernel");
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_begins, d_ends, (uint32_t)n_seqs, blocksum, total, chunk_start, rec_of_chunk);
-    PO_CHECK_LAUNCH("scan_apply_kernel");
+    const bool one_pass = nb <= kOnePassBlocks && pat.dim >= 4 && pat.dim <= kMaxLdsBins;
+    const bool zero_by_kernel = one_pass && (reinterpret_cast<uintptr_t>(d_counts) & 15u) == 0;      // (its stores are 16 bytes wide)
+    if (one_pass && !zero_by_kernel) PO_HIP(hipMemsetAsync(d_counts, 0, n_seqs * (uint64_t)pat.dim * sizeof(uint32_t), ctx->stream));
+    if (one_pass) {
+        // one launch for the scan (which also zeroes the word totals); the rows that need zeros get them further down, once the
+        // launch geometry of the counting kernel is known
+        const size_t need = (2 * (size_t)kOnePassBlocks) * sizeof(unsigned long long) + 64;
+        if (ctx->ws_scan.cap < need) {
+            rc = po_buf_reserve(ctx, &ctx->ws_scan, need);
+            if (rc) return rc;
+            PO_HIP(hipMemsetAsync(ctx->ws_scan.p, 0, ctx->ws_scan.cap, ctx->stream));
+            ctx->scan_epoch = 0;
+        }
+        if (++ctx->scan_epoch == 0u) {                              // the tag wrapped: start over from a clean buffer
+            PO_HIP(hipMemsetAsync(ctx->ws_scan.p, 0, ctx->ws_scan.cap, ctx->stream));
+            ctx->scan_epoch = 1;
+        }
+        unsigned long long* agg = static_cast<unsigned long long*>(ctx->ws_scan.p);
+        unsigned long long* big = agg + kOnePassBlocks;
+        uint32_t* ticket = reinterpret_cast<uint32_t*>(big + kOnePassBlocks);
+        hipLaunchKernelGGL(scan_chunks_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_begins, d_ends, (uint32_t)n_seqs, nb, agg, big, ticket,
+                           ticket + 1, ctx->scan_epoch, chunk_start, rec_of_chunk, d_max_chunks, reinterpret_cast<unsigned long long*>(d_totals));
+        PO_CHECK_LAUNCH("scan_chunks_kernel");
+    } else {
+        // every row and every total zeroed, three launches for the scan
+        PO_HIP(hipMemsetAsync(d_counts, 0, n_seqs * (uint64_t)pat.dim * sizeof(uint32_t), ctx->stream));
+        PO_HIP(hipMemsetAsync(d_totals, 0, n_seqs * sizeof(uint64_t), ctx->stream));
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_begins, d_ends, (uint32_t)n_seqs, blocksum, blockmax);
+        PO_CHECK_LAUNCH("scan_block_sums_kernel");
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, blocksum, nb, total, blockmax, d_max_chunks);
+        PO_CHECK_LAUNCH("scan_sums_kernel");
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_begins, d_ends, (uint32_t)n_seqs, blocksum, total, chunk_start, rec_of_chunk);
+        PO_CHECK_LAUNCH("scan_apply_kernel");
+    }
 
     CountParams P;
     memset(&P, 0, sizeof(P));
@@ -895,6 +1028,12 @@ int po_launch_count(po_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_begins,
     const size_t shmem = per_wave * wpb;
     const uint32_t grid = (uint32_t)((max_chunks + wpb - 1) / wpb);
     unsigned long long* tot = reinterpret_cast<unsigned long long*>(d_totals);
+    if (zero_by_kernel) {
+        const uint32_t* empty_tag = reinterpret_cast<const uint32_t*>(static_cast<unsigned long long*>(ctx->ws_scan.p) + 2 * kOnePassBlocks) + 1;
+        hipLaunchKernelGGL(zero_rows_kernel, dim3(2048), dim3(256), 0, ctx->stream, chunk_start, d_max_chunks, empty_tag, ctx->scan_epoch,
+                           (uint32_t)n_seqs, pat.dim, wpb, d_counts);
+        PO_CHECK_LAUNCH("zero_rows_kernel");
+    }
     const int width = 2 * pat.window <= 32 ? 0 : (pat.window <= 32 ? 1 : 2);
     const int mode = (strand == PO_STRAND_PLUS || P.sym) ? 0 : (strand == PO_STRAND_MINUS ? 1 : 2);
     auto launch = [&](auto k) -> int {

@@ -64,6 +64,8 @@ struct po_ctx {
     uint64_t pq_key = ~0ull;
     po_buf ws_thermo;                  // Bray-Curtis thermometer plan (levels per word, element map)
     po_buf ws_seg;                     // stage 1: segment rows of long records (po_count.hip), all zero between calls
+    po_buf ws_scan;                    // stage 1: per-workgroup aggregates of the one-launch chunk scan, tagged with scan_epoch
+    uint32_t scan_epoch = 0;           // (entries of older calls carry older tags: the buffer is never cleared between calls)
     po_buf ws_fasta;                   // per-block partial results of the on-device FASTA scan (po_fasta.hip)
     const uint8_t* fasta_data = nullptr;   // the buffer po_fasta_scan_dev last sized, with its length and totals
     uint64_t fasta_len = 0, fasta_records = 0, fasta_seq_bytes = 0;
