@@ -50,6 +50,15 @@ def _oracle_profiles(seqs):
     return po.compute_frequencies(seqs, "1111", "both")
 
 
+def _oracle_profiles_per_window(seqs):
+    """the reference's own way: one Python string per window (phyloligo.py:622-631)"""
+    from oracle import phyloligo_oracle as po
+    t0 = time.perf_counter()
+    for s in seqs:
+        po.profile_counts_per_window(s, "1111", "both")
+    return time.perf_counter() - t0
+
+
 def usable_cores():
     """CPUs this process may actually use: the affinity mask, cut down to the cgroup CPU quota when there is one
     (a GPU box shows all 256 hardware threads of the host to os.cpu_count() but gives a one-GPU job a share of them)."""
@@ -122,8 +131,18 @@ def cpu_baseline(freq, metric, budget_s=10.0, cores=None):
         par(joblib.delayed(_oracle_rows)(f1, "Eucl", list(range(c * per, min(1000, (c + 1) * per)))) for c in range(cores)
             if c * per < 1000)
         t_dist = time.perf_counter() - t0
+        # stage 1 as the reference runs it - a Python string per window - on 4 contigs per process, scaled to the 1 000
+        sample = 4
+        t0 = time.perf_counter()
+        per_core = par(joblib.delayed(_oracle_profiles_per_window)(seqs[c * sample:(c + 1) * sample]) for c in range(cores))
+        t_pw = (time.perf_counter() - t0) * (1000.0 / (sample * cores))
     out["c1_full"] = {"workload": "BASELINE config 1: 1 000 contigs x 2 kb (seed 1001), k=4 both strands, -d Eucl, whole job",
-                      "profiles_s": t_prof, "distances_s": t_dist, "pairs_per_s": 499500.0 / t_dist,
+                      "profiles_s": t_prof, "profiles_kind": "oracle.count_pattern: vectorised numpy (one bincount per record), NOT the "
+                      "reference's per-window Python loop - see profiles_per_window_s",
+                      "profiles_per_window_s": t_pw, "profiles_per_window_kind": "oracle.profile_counts_per_window (a Python string per "
+                      "window, as bin/phyloligo.py:622-631): %d contigs per process timed on %d processes, scaled to 1 000; "
+                      "per-core seconds per contig: %.4f" % (sample, cores, sum(per_core) / (sample * cores)),
+                      "distances_s": t_dist, "pairs_per_s": 499500.0 / t_dist,
                       "metric_calls": 1000 * 1000, "cores": cores}
     return out
 
@@ -298,11 +317,14 @@ def main():
     # one-GPU box: process group, all_gather_into_tensor, barrier, all_reduce)
     if world > 1 or os.environ.get("PO_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if rehearsal:
-            dist.init_process_group("gloo")
+        from phyloligo_amd.dist import first_contact
+        first_contact("cuda.set_device", torch.cuda.set_device, local_rank)
+        # (PO_BENCH_BACKEND: a backend name for the failure drill of tests/test_dist_gloo.py; unset in every real run)
+        backend = os.environ.get("PO_BENCH_BACKEND") or ("gloo" if rehearsal else "nccl")
+        if backend == "nccl":
+            first_contact("init_process_group", dist.init_process_group, "nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            first_contact("init_process_group", dist.init_process_group, backend)
     else:
         dist = None
     if world != args.gpus:               # started under torch.distributed.run with a different --nproc-per-node
@@ -337,10 +359,16 @@ def main():
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
     if rehearsal and dist is not None:
-        counts, totals = plan.all_gather_profiles(my_counts.cpu(), my_totals.cpu(), dist)
+        counts, totals = first_contact("all_gather_profiles", plan.all_gather_profiles, my_counts.cpu(), my_totals.cpu(), dist)
         counts, totals = counts.to(dev), totals.to(dev)
+    elif dist is not None:
+        def gather():                     # the path's one exchange and the ranks' first collective: failures surface at the synchronize
+            c, t = plan.all_gather_profiles(my_counts, my_totals, dist, force=True)
+            torch.cuda.synchronize(dev)
+            return c, t
+        counts, totals = first_contact("all_gather_profiles", gather)
     else:
-        counts, totals = plan.all_gather_profiles(my_counts, my_totals, dist, force=dist is not None)
+        counts, totals = my_counts, my_totals
     if dist is not None:
         torch.cuda.synchronize(dev)
         allgather_ms = (time.perf_counter() - t0) * 1e3
@@ -497,6 +525,7 @@ def main():
                 "complete_rows_ms": complete_rows_ms,
                 "kernel_ms_min": min(rank_kernel_ms), "kernel_ms_max": max(rank_kernel_ms), "kernel_ms_per_rank": rank_kernel_ms,
                 "pairs_rank0": rank_pairs,
+                "environment": __import__("phyloligo_amd.dist", fromlist=["dist_environment"]).dist_environment(),
                 "note": "all-gather = the single exchange of the path, outside the timed region like stage 1; "
                         "complete_rows = optional second exchange delivering mirror blocks to row owners, not part of `value`"}
         if world == 1 and args.metric == "JSD" and n == 50000 and not args.no_other_configs:

@@ -130,6 +130,30 @@ def profile_counts(seq, pattern="1111", strand="both") -> tuple[np.ndarray, int]
     return count_pattern(select_strand(encode(seq), strand), pattern)
 
 
+def profile_counts_per_window(seq, pattern="1111", strand="both") -> tuple[np.ndarray, int]:
+    """The same integers the way the reference obtains them - one Python string per window (phyloligo.py:124-149 strand
+    selection on the upper-cased text, :622-631 split at everything that is not A/C/G/T and join the pattern's '1' positions of
+    every window, Counter; :653 the dense C,G,A,T word order).  Pure-Python loops: for small cases, and for the
+    cpu_baseline leg of bench.py, which times THIS on a sample because count_pattern() above (numpy, one bincount per
+    record) is ~15 x faster than what the reference actually runs per core (SURVEY: 2.87 s per 1 000 contigs of 2 kb)."""
+    import collections
+    import itertools
+    import re
+    pattern, W, k, ones = pattern_info(pattern)
+    text = _as_bytes(seq).decode("latin-1").upper()
+    if strand != "plus":
+        rc = text[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        text = rc if strand == "minus" else text + rc
+        if strand not in ("minus", "both"):
+            raise ValueError("strand must be one of both/plus/minus")
+    words: collections.Counter = collections.Counter()
+    for piece in re.split("[^ACGT]+", text):
+        for start in range(len(piece) - W + 1):
+            words["".join(piece[start + o] for o in ones)] += 1
+    dense = np.array([words.get("".join(w), 0) for w in itertools.product("CGAT", repeat=k)], dtype=np.int64)
+    return dense, int(sum(words.values()))
+
+
 def compute_frequency(seq, pattern="1111", strand="both") -> np.ndarray:
     """phyloligo.py:663-691."""
     counts, total = profile_counts(seq, pattern, strand)

@@ -20,7 +20,59 @@ in HBM on the rank that evaluated the pair; `complete_rows` is the optional seco
 point over xGMI) that sends each mirror buffer to the rank whose row slab it belongs to, for
 consumers that want row-complete slabs (e.g. writing the .mat).
 """
+import json
+import os
+import sys
+
 import numpy as np
+
+# what the ranks of a multi-GPU run inherit and what decides whether RCCL comes up at all: reported with every N > 1 record and
+# with every first-contact failure (no process group of more than one GPU has ever run this code - see DESIGN section 6)
+_ENV_PREFIXES = ("HSA_", "NCCL_", "RCCL_", "HIP_", "ROCR_", "GPU_", "MASTER_", "TORCH_NCCL_", "PO_")
+_ENV_NAMES = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "OMP_NUM_THREADS", "CUDA_VISIBLE_DEVICES")
+
+
+def dist_environment():
+    """The environment a rank runs under, as it goes into the bench record (`config.multi_gpu.environment`) and into the
+    error line of a failed first contact: the variables that steer HSA / RCCL / the launcher, the torch and RCCL versions.
+    HSA_ENABLE_IPC_MODE_LEGACY is named even when unset: launch.spawn_ranks sets it to 0 (dmabuf IPC) unless the caller
+    has set it, on the strength of a ONE-rank RCCL test - the first run on several GPUs is where that gets verified."""
+    env = {k: v for k, v in sorted(os.environ.items()) if k.startswith(_ENV_PREFIXES) or k in _ENV_NAMES}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "(unset)")
+    info = {"env": env}
+    try:
+        import torch
+        info["torch"] = torch.__version__
+        info["hip"] = getattr(torch.version, "hip", None)
+        try:
+            info["rccl"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as exc:                        # no GPU build / no device: say so instead of failing the report
+            info["rccl"] = "unavailable (%s)" % type(exc).__name__
+        info["devices_visible"] = torch.cuda.device_count()
+    except Exception as exc:
+        info["torch"] = "unavailable (%s)" % type(exc).__name__
+    return info
+
+
+def first_contact(stage, fn, *args, **kwargs):
+    """Run one step of bringing the ranks together (init_process_group, the first collective).  If it raises, the rank says so in
+    ONE JSON line - on stdout for rank 0, the line the driver parses; on stderr for the others - with the stage, the error and the
+    environment it ran under, and exits with status 3: torch.distributed.run then takes the other ranks down and
+    launch.spawn_ranks hands the status on.  A run that cannot start must not look like a hang or a Python traceback lottery."""
+    try:
+        return fn(*args, **kwargs)
+    except BaseException as exc:                         # (KeyboardInterrupt / SystemExit included: still a failed start)
+        rank = int(os.environ.get("RANK", "0"))
+        line = {"error": "%s: %s" % (type(exc).__name__, exc), "stage": stage, "rank": rank,
+                "world_size": int(os.environ.get("WORLD_SIZE", "1"))}
+        line.update(dist_environment())
+        out = sys.stdout if rank == 0 else sys.stderr
+        out.write(json.dumps(line) + "\n")
+        out.flush()
+        if rank != 0:                                    # the launcher takes every rank down when the first one exits: leave
+            import time                                  # rank 0 - which usually fails for the same reason at the same moment -
+            time.sleep(3.0)                              # the time to get its line out
+        sys.exit(3)
 
 
 class RowBlockPlan:

@@ -424,11 +424,12 @@ def main_distributed(params):
             sys.exit(1)
     if params.strand not in STRANDS or params.dist not in METRICS:
         sys.exit(1)
-    torch.cuda.set_device(local)
+    from .dist import first_contact
+    first_contact("cuda.set_device", torch.cuda.set_device, local)
     if rehearsal:
-        tdist.init_process_group("gloo")
+        first_contact("init_process_group", tdist.init_process_group, "gloo")
     else:
-        tdist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        first_contact("init_process_group", tdist.init_process_group, "nccl", device_id=torch.device("cuda", local))
     global _ctx
     _ctx = api.Context(local)
     ctx, dev = _ctx, torch.device("cuda", local)
@@ -452,10 +453,14 @@ def main_distributed(params):
         my_seq = my_seq.clone()
     my_counts, my_totals = ctx.count_profiles(my_seq, my_off, params.pattern, params.strand)
     if rehearsal:
-        counts, totals = plan.all_gather_profiles(my_counts.cpu(), my_totals.cpu(), tdist)
+        counts, totals = first_contact("all_gather_profiles", plan.all_gather_profiles, my_counts.cpu(), my_totals.cpu(), tdist)
         counts, totals = counts.to(dev), totals.to(dev)
     else:
-        counts, totals = plan.all_gather_profiles(my_counts, my_totals, tdist)
+        def gather():                     # the ranks' first collective: a failure surfaces at the synchronize at the latest
+            c, t = plan.all_gather_profiles(my_counts, my_totals, tdist)
+            torch.cuda.synchronize(dev)
+            return c, t
+        counts, totals = first_contact("all_gather_profiles", gather)
     say("Computing Pairwise distances")
     t_dist0 = time.perf_counter()
     dtype = torch.float32 if params.large in ("memmap", "h5py") else torch.float64

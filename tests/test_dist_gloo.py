@@ -150,3 +150,39 @@ def test_launcher_starts_ranks_relays_output_and_status(tmp_path):
     chk = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\nfrom phyloligo_amd import launch\n"
                           "sys.exit(1 if launch.needs_launcher(8) else 0)" % root], env=env2, timeout=60)
     assert chk.returncode == 0
+
+
+def test_first_contact_failure_is_one_json_line_and_a_status(tmp_path):
+    """no process group of more than one GPU has ever run this code, so the first 8-GPU run must fail
+    LEGIBLY if it fails - rank 0 prints one JSON line with the stage, the error and the environment (HSA_ENABLE_IPC_MODE_LEGACY
+    named even when unset, RCCL / torch versions), every rank exits with status 3 and the launcher hands a non-zero status on.
+    Driven on the CPU with a backend that does not exist, two ranks under launch.spawn_ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rank_script = tmp_path / "rank.py"
+    rank_script.write_text(
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch.distributed as dist\n"
+        "from phyloligo_amd.dist import first_contact\n"
+        "first_contact('init_process_group', dist.init_process_group, sys.argv[1])\n"
+        "ok = first_contact('all_gather_profiles', lambda: 7)\n"
+        "print('CONTACT', ok, flush=True)\n"
+        "dist.destroy_process_group()\n" % root)
+    driver = ("import sys; sys.path.insert(0, %r)\n"
+              "from phyloligo_amd import launch\n"
+              "sys.exit(launch.spawn_ranks(2, [%r], [sys.argv[1]], timeout_s=120.0))\n") % (root, str(rank_script))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "HSA_ENABLE_IPC_MODE_LEGACY")}
+    bad = subprocess.run([sys.executable, "-c", driver, "no_such_backend"], capture_output=True, text=True, timeout=300, env=env)
+    assert bad.returncode != 0
+    lines = [json.loads(l) for l in bad.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, bad.stdout[-2000:]                       # rank 0 alone writes to stdout
+    rec = lines[0]
+    assert rec["stage"] == "init_process_group" and rec["rank"] == 0 and rec["world_size"] == 2 and "no_such_backend" in rec["error"]
+    assert rec["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"          # what launch.spawn_ranks put there (nobody had set it)
+    assert rec["env"]["WORLD_SIZE"] == "2" and "MASTER_PORT" in rec["env"] and "torch" in rec and "rccl" in rec
+    # (the other rank reports on stderr - if torch.distributed.run has not taken it down first)
+    ok = subprocess.run([sys.executable, "-c", driver, "gloo"], capture_output=True, text=True, timeout=300, env=env)
+    assert ok.returncode == 0 and ok.stdout.count("CONTACT 7") == 2, ok.stderr[-2000:]

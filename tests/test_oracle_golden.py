@@ -32,6 +32,18 @@ def test_counts_bit_exact(prof, pattern, strand):
     assert np.array_equal(freq, prof["freq_%s_%s" % (pattern, strand)])  # bit-exact float64
 
 
+@pytest.mark.parametrize("pattern,strand", [("1111", "both"), ("1101", "minus"), ("10011", "plus"), ("11", "both")])
+def test_per_window_restatement_equals_the_vectorised_counter_and_the_reference(prof, pattern, strand):
+    """oracle.profile_counts_per_window walks the windows one Python string at a time, as the reference does (the cost model of
+    bench.py's cpu_baseline stage-1 figure); same integers as the numpy counter and as the reference's own vectors."""
+    contigs = [bytes(c) for c in prof["contigs"]][:12] + [b"acgtNNacgtRYacg", b"", b"ACG", b"NNNN"]
+    want_c, want_t = po.compute_counts(contigs, pattern, strand)
+    for i, c in enumerate(contigs):
+        got_c, got_t = po.profile_counts_per_window(c, pattern, strand)
+        assert got_t == want_t[i] and np.array_equal(got_c, want_c[i])
+    assert np.array_equal(want_c[:12], prof["counts_%s_%s" % (pattern, strand)][:12])
+
+
 def test_known_answers(prof):
     # facts verified against the imported reference at survey time (SURVEY.md 8c)
     c, t = po.profile_counts("ACGT", "1111", "plus")
