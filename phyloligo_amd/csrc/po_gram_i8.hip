@@ -558,7 +558,11 @@ __global__ __launch_bounds__(kQuadThreads, 4) void gram_i8_quad_kernel(po_tile_a
         po_lds_barrier();                                  // terms in place (h = 0); the stores of the upper half have read the scratch (h = 1)
         gram_i8_values_to_tile<1, METRIC, 2>(g[h], terms, h * 64 + wr * 32, wr * 32, wc, lr_e, lh_e, ti == tj, tl);
         po_lds_barrier();
-        po_store_tile_f32<kQuadThreads / 64, 64>(A, mirror, i0 + h * 64, j0, wave, lane_e, tl);
+        // (the lane index once more, per pass: store addresses shared between the passes would stay live across the second pass's
+        //  arithmetic - next to its 32 accumulators - and spill)
+        uint32_t lane_s;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+        po_store_tile_f32<kQuadThreads / 64, 64>(A, mirror, i0 + h * 64, j0, wave, lane_s, tl);
     }
 }
 

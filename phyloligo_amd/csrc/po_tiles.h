@@ -211,9 +211,83 @@ constexpr int kF32TileBytes = 128 * kF32TileStride * 4;              // 66 560 B
 
 typedef float po_f4v __attribute__((ext_vector_type(4)));
 
+// VW consecutive floats of the scratch as one store: 16, 8 or 4 bytes
+template <int VW> struct po_f32_vec;
+template <> struct po_f32_vec<4> { typedef po_f4v type; };
+template <> struct po_f32_vec<2> { typedef po_f2v type; };
+template <> struct po_f32_vec<1> { typedef float type; };
+
+// Rows i0 .. i0 + ROWS - 1 of a tile that lies inside its block, as stores of VW floats: a row is 128 / VW lanes, a wave
+// instruction covers 64 VW / 128 rows (VW = 4: two rows, 16-byte stores of 512-byte pieces).  `dst` = the matrix entry of (row 0,
+// column 0) of the piece; the scratch holds the piece row-major (TRANSPOSED = false) or column-major (true: the piece is the
+// transposed tile, its rows are columns of the scratch and ROWS counts its COLUMNS).
+template <int NW, int ROWS, int VW, bool TRANSPOSED>
+__device__ __forceinline__ void po_store_piece_f32(float* dst, uint64_t ld, uint32_t wave, uint32_t lane, const float* tl) {
+    typedef typename po_f32_vec<VW>::type vec;
+    constexpr int WIDTH = TRANSPOSED ? ROWS : 128, NROWS = TRANSPOSED ? 128 : ROWS;     // shape of the piece in the matrix
+    constexpr int LPR = WIDTH / VW;                                  // lanes per row
+    if constexpr (LPR <= 64) {
+        constexpr int RPI = 64 / LPR, IT = NROWS / RPI / NW;          // rows per instruction, instructions per wave
+        const uint32_t q = lane / LPR, m = lane % LPR;
+        const uint32_t r0 = RPI * (wave & (NW - 1)) + q;
+        float* out = dst + (uint64_t)r0 * ld + VW * m;
+        const uint64_t step = (uint64_t)RPI * NW * ld;
+        vec v[IT];
+        // (all LDS reads of the wave first, then its stores; the wave index is known to be below NW, so the trip count is fixed)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const uint32_t r = r0 + it * RPI * NW;
+            if constexpr (!TRANSPOSED) {
+                const float* src = tl + r * kF32TileStride + VW * m;
+                if constexpr (VW == 4) { const float2 a = *reinterpret_cast<const float2*>(src), b = *reinterpret_cast<const float2*>(src + 2); v[it] = vec{a.x, a.y, b.x, b.y}; }
+                else if constexpr (VW == 2) { const float2 a = *reinterpret_cast<const float2*>(src); v[it] = vec{a.x, a.y}; }
+                else v[it] = src[0];
+            } else {
+                const float* src = tl + VW * m * kF32TileStride + r;
+                if constexpr (VW == 4) v[it] = vec{src[0], src[kF32TileStride], src[2 * kF32TileStride], src[3 * kF32TileStride]};
+                else if constexpr (VW == 2) v[it] = vec{src[0], src[kF32TileStride]};
+                else v[it] = src[0];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) __builtin_nontemporal_store(v[it], reinterpret_cast<vec*>(out + it * step));
+    } else {                                                          // 128 single floats per row: two instructions per row
+        constexpr int IT = NROWS / NW, GRP = IT < 8 ? IT : 8;         // (eight rows of reads, then their stores: 16 registers)
+        const uint32_t r0 = wave & (NW - 1);
+        float* out = dst + (uint64_t)r0 * ld + lane;
+        const uint64_t step = (uint64_t)NW * ld;
+#pragma unroll 1
+        for (int g = 0; g < IT; g += GRP) {
+            float v[GRP][2];
+#pragma unroll
+            for (int it = 0; it < GRP; ++it) {
+                const uint32_t r = r0 + (g + it) * NW;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    v[it][h] = TRANSPOSED ? tl[(lane + 64 * h) * kF32TileStride + r] : tl[r * kF32TileStride + lane + 64 * h];
+            }
+#pragma unroll
+            for (int it = 0; it < GRP; ++it) {
+                __builtin_nontemporal_store(v[it][0], out + (g + it) * step);
+                __builtin_nontemporal_store(v[it][1], out + (g + it) * step + 64);
+            }
+        }
+    }
+}
+
+// The widest store a piece allows: 4 floats when its rows start on 16-byte boundaries, 2 on 8-byte boundaries, else single floats
+__device__ __forceinline__ int po_f32_store_width(const void* base, uint64_t ld, uint64_t first) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+    if ((ld & 3) == 0 && (first & 3) == 0 && (a & 15) == 0) return 4;
+    if ((ld & 1) == 0 && (first & 1) == 0 && (a & 7) == 0) return 2;
+    return 1;
+}
+
 // All NW waves of the workgroup call this after the values sit in `tl` and a barrier has made them visible.  ROWS = 128: the whole
 // tile; ROWS = 64: one half of it, rows i0 .. i0 + 63 (a kernel that keeps half the scratch - 33 KiB - and makes two passes: its
-// transposed rows then leave as 256-byte pieces).
+// transposed rows then leave as 256-byte pieces).  Tiles inside their block go out without a per-lane test, as 16-byte stores
+// when the rows of the matrix start on 16-byte boundaries (a leading dimension that is a multiple of 4 entries; of 32 entries
+// = whole 128-byte lines is better still, and is what this library's own buffers have), as 8- or 4-byte stores otherwise.
 template <int NW, int ROWS = 128>
 __device__ __forceinline__ void po_store_tile_f32(const po_tile_args& A, bool mirrors, uint64_t i0, uint64_t j0, uint32_t wave,
                                                   uint32_t lane, const float* tl) {
@@ -224,24 +298,13 @@ __device__ __forceinline__ void po_store_tile_f32(const po_tile_args& A, bool mi
     if (A.n != 0x7fffffffffffffffull) return;                        // isolating build: everything but the global stores
 #endif
     const bool inside = i0 >= A.row_begin && i0 + ROWS <= n_rows && j0 >= A.col_begin && j0 + 128 <= n_cols;   // uniform
-    // ---- the rows themselves: lanes 0..31 one row, lanes 32..63 the next, four columns each ----
-    if (inside && (A.ld_out & 3) == 0 && ((j0 - A.col_begin) & 3) == 0 && (reinterpret_cast<uintptr_t>(A.out) & 15) == 0) {
-        // (all LDS reads of the wave first, then its stores; the wave index is known to be below NW, so the trip count is fixed)
-        constexpr int IT = ROWS / 2 / NW;
-        const uint32_t half = lane >> 5, m = lane & 31;
-        const uint32_t r0 = 2 * (wave & (NW - 1)) + half;
-        float* dst = out + (i0 - A.row_begin + r0) * A.ld_out + (j0 - A.col_begin) + 4 * m;
-        const uint64_t step = 2 * NW * A.ld_out;
-        const float* src = tl + r0 * kF32TileStride + 4 * m;
-        po_f4v v[IT];
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const float2 a = *reinterpret_cast<const float2*>(src + it * 2 * NW * kF32TileStride);
-            const float2 b = *reinterpret_cast<const float2*>(src + it * 2 * NW * kF32TileStride + 2);
-            v[it] = po_f4v{a.x, a.y, b.x, b.y};
-        }
-#pragma unroll
-        for (int it = 0; it < IT; ++it) __builtin_nontemporal_store(v[it], reinterpret_cast<po_f4v*>(dst + it * step));
+    // ---- the rows themselves ----
+    if (inside) {
+        float* dst = out + (i0 - A.row_begin) * A.ld_out + (j0 - A.col_begin);
+        const int vw = po_f32_store_width(A.out, A.ld_out, j0 - A.col_begin);
+        if (vw == 4) po_store_piece_f32<NW, ROWS, 4, false>(dst, A.ld_out, wave, lane, tl);
+        else if (vw == 2) po_store_piece_f32<NW, ROWS, 2, false>(dst, A.ld_out, wave, lane, tl);
+        else po_store_piece_f32<NW, ROWS, 1, false>(dst, A.ld_out, wave, lane, tl);
     } else {
         for (uint32_t r = wave; r < ROWS; r += NW) {
             const uint64_t i = i0 + r;
@@ -255,23 +318,14 @@ __device__ __forceinline__ void po_store_tile_f32(const po_tile_args& A, bool mi
         }
     }
     if (!mirrors) return;
-    // ---- the transposed rows (columns of tl): ROWS / 4 lanes per transposed row, four entries each ----
+    // ---- the transposed rows (columns of tl) ----
     float* mir = static_cast<float*>(A.mirror);
-    if (inside && (A.ld_mirror & 3) == 0 && ((i0 - A.row_begin) & 3) == 0 && (reinterpret_cast<uintptr_t>(A.mirror) & 15) == 0) {
-        constexpr int LPR = ROWS / 4, RPI = 64 / LPR, IT = 128 / RPI / NW;      // lanes per row, rows per instruction, instructions per wave
-        const uint32_t q = lane / LPR, m = lane % LPR;
-        const uint32_t c0 = RPI * (wave & (NW - 1)) + q;
-        float* dst = mir + (j0 - A.col_begin + c0) * A.ld_mirror + (i0 - A.row_begin) + 4 * m;
-        const uint64_t step = RPI * NW * A.ld_mirror;
-        const float* src = tl + 4 * m * kF32TileStride + c0;
-        po_f4v v[IT];
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const float* e = src + it * RPI * NW;
-            v[it] = po_f4v{e[0], e[kF32TileStride], e[2 * kF32TileStride], e[3 * kF32TileStride]};
-        }
-#pragma unroll
-        for (int it = 0; it < IT; ++it) __builtin_nontemporal_store(v[it], reinterpret_cast<po_f4v*>(dst + it * step));
+    if (inside) {
+        float* dst = mir + (j0 - A.col_begin) * A.ld_mirror + (i0 - A.row_begin);
+        const int vw = po_f32_store_width(A.mirror, A.ld_mirror, i0 - A.row_begin);
+        if (vw == 4) po_store_piece_f32<NW, ROWS, 4, true>(dst, A.ld_mirror, wave, lane, tl);
+        else if (vw == 2) po_store_piece_f32<NW, ROWS, 2, true>(dst, A.ld_mirror, wave, lane, tl);
+        else po_store_piece_f32<NW, ROWS, 1, true>(dst, A.ld_mirror, wave, lane, tl);
     } else {
         for (uint32_t c = wave; c < 128; c += NW) {
             const uint64_t j = j0 + c;

@@ -240,3 +240,31 @@ def test_eucl_tiles_dealt_to_the_plane_kernels_by_class(ctx):
         for b in blocks:
             (r0, r1), (c0, c1) = b["rows"], b["cols"]
             assert bool(torch.equal(b["out"], full[r0:r1, c0:c1])) and bool(torch.equal(b["mirror"], full[c0:c1, r0:r1]))
+
+
+@pytest.mark.parametrize("n", [1301, 1302, 1304])
+def test_float32_store_widths_for_every_alignment_of_the_rows(ctx, n):
+    """Round 5: float32 tiles leave through an LDS scratch as 16-byte stores when the rows of the output start on 16-byte
+    boundaries, as 8-byte stores on 8-byte boundaries, as single floats otherwise (odd leading dimension) - and element by element,
+    with bounds tests, on the edge tiles.  Contiguous n x n outputs with n = 1 301 / 1 302 / 1 304 take the three widths; a block
+    that starts inside a tile (rows 77 .., a view whose first column is not a multiple of 4) takes the guarded path.  Eucl (one
+    and two digit planes), SC and BC (packed SAD kernel): float32 == the float64 result rounded once, entry for entry."""
+    import torch
+    rng = np.random.default_rng(n)
+    dim = 256
+    base = rng.integers(0, 40, size=dim)
+    counts = np.stack([rng.permutation(base) for _ in range(n)]).astype(np.uint32)      # one common total: the SAD kernel takes BC
+    totals = counts.sum(1).astype(np.uint64)
+    big = counts.copy()
+    big[5] = rng.permutation(np.concatenate([[3000], rng.integers(0, 300, size=dim - 1)]))   # two digit planes for Eucl
+    cases = (("Eucl", counts, totals), ("Eucl", big, big.sum(1).astype(np.uint64)), ("SC", counts, totals), ("BC", counts, totals))
+    for metric, c, t in cases:
+        dc, dt = torch.from_numpy(c.view(np.int32)).cuda(), torch.from_numpy(t.view(np.int64)).cuda()
+        f64 = torch.empty((n, n), dtype=torch.float64, device="cuda")
+        ctx.pairwise(dc, dt, metric, out=f64)
+        f32 = torch.full((n, n), float("nan"), dtype=torch.float32, device="cuda")
+        ctx.pairwise(dc, dt, metric, out=f32, dtype="float32")
+        assert bool(torch.equal(f32, f64.to(torch.float32))), (metric, n)
+        wide = torch.full((n - 77, n + 3), float("nan"), dtype=torch.float32, device="cuda")   # rows 77 .., written at column 3
+        ctx.pairwise(dc, dt, metric, out=wide[:, 3:], dtype="float32", row_begin=77, row_end=n)
+        assert bool(torch.equal(wide[:, 3:], f64[77:].to(torch.float32))) and bool(torch.isnan(wide[:, :3]).all()), (metric, n)
