@@ -175,9 +175,6 @@ __global__ __launch_bounds__(256) void classify_tiles_kernel(po_tile_args A, con
 template <int METRIC>
 __device__ __forceinline__ double gram_i8_value(const double G, const double t0r, const double t1r, const double* t2r,
                                                 const double t0c, const double t1c, const double* t2c, const bool same) {
-#if defined(PO_EXP_NOMATH)
-    return G * t0c + t0r;                                  // isolating build: the stores without the distance arithmetic
-#endif
     if (METRIC == PO_EUCL) {
         const double sum = t0r + t0c;
         double d2 = fmax(fma(G, (-2.0 * t1r) * t1c, sum), 0.0);
@@ -212,11 +209,6 @@ template <int METRIC, int N>
 __device__ __forceinline__ uint32_t gram_i8_values_fast(const double (&G)[N], const double (&t0r)[N], const double (&t1r)[N],
                                                         const double (&t0c)[N], const double (&t1c)[N], float (&out)[N]) {
     uint32_t special = 0;
-#if defined(PO_EXP_NOMATH)
-#pragma unroll
-    for (int e = 0; e < N; ++e) out[e] = (float)(G[e] * t0c[e] + t0r[e]);
-    return 0;
-#endif
     double x[N], y[N];
     if (METRIC == PO_EUCL) {
         double gg[N], h[N], r[N];
@@ -746,7 +738,6 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
     const size_t staging = (size_t)P * 2 * 8 * kChunkBytes;
     const size_t scratch = a.out_f32 ? (size_t)kF32TileBytes : (size_t)kMirrorBytes;      // the epilogue's LDS, over the staging area
     const size_t shmem = (staging > scratch ? staging : scratch) + kTermBytes;
-#if !defined(PO_EXP_NO_QUAD)
     if constexpr (P == 1) if (a.out_f32) {
         auto k = gram_i8_quad_kernel<METRIC>;
         PO_SHMEM(ctx, k, (size_t)kQuadLdsBytes);
@@ -754,8 +745,6 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
         PO_CHECK_LAUNCH("gram_i8_quad_kernel");
         return PO_OK;
     }
-#endif
-#if !defined(PO_EXP_NO_STREAM)
     // (three planes: five accumulator groups = 160 registers of the 168 a wave of a nine-wave workgroup may have - those tiles, the
     //  few that hold a record of more than ~1 Mb, stay with the tile kernel and its float32 tile epilogue)
     if constexpr (P == 2) if (a.out_f32) {
@@ -769,11 +758,12 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
         PO_CHECK_LAUNCH("gram_i8_stream_kernel");
         return PO_OK;
     }
-#endif
     if (a.out_f32) {
-        auto k = gram_i8_tile_kernel<P, METRIC, float>;
-        PO_SHMEM(ctx, k, shmem);
-        hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
+        if constexpr (P == 3) {                            // (one and two planes returned above)
+            auto k = gram_i8_tile_kernel<P, METRIC, float>;
+            PO_SHMEM(ctx, k, shmem);
+            hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
+        }
     } else {
         auto k = gram_i8_tile_kernel<P, METRIC, double>;
         PO_SHMEM(ctx, k, shmem);

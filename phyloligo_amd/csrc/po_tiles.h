@@ -294,9 +294,6 @@ __device__ __forceinline__ void po_store_tile_f32(const po_tile_args& A, bool mi
     static_assert(ROWS == 128 || ROWS == 64, "whole tiles or halves");
     float* out = static_cast<float*>(A.out);
     const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
-#if defined(PO_EXP_NOSTORE)
-    if (A.n != 0x7fffffffffffffffull) return;                        // isolating build: everything but the global stores
-#endif
     const bool inside = i0 >= A.row_begin && i0 + ROWS <= n_rows && j0 >= A.col_begin && j0 + 128 <= n_cols;   // uniform
     // ---- the rows themselves ----
     if (inside) {
