@@ -581,7 +581,9 @@ def main():
                             best = s2
                     bpp32 = 8 + 2 * dim * 4 / (n - 1)
                     f32[m] = {"ms": best["total_ms"], "kernel_ms": best["kernel_ms"], "kernel_id": best["kernel_id"],
-                              "kernel": KERNEL_NAMES.get(best["kernel_id"]), "roofline": hbm_roofline(bpp32 * pairs, best["kernel_ms"], bytes_per_pair=bpp32)}
+                              "kernel": KERNEL_NAMES.get(best["kernel_id"]),
+                              "roofline": hbm_roofline(bpp32 * pairs, best["kernel_ms"], bytes_per_pair=bpp32,
+                                                       traffic=traffic_all.get({"BC": "BC_sad_f32_n%d_d%d"}.get(m, m + "_f32_n%d_d%d") % (n, dim)))}
                 others["C2-size float32 matrix (10 GB)"] = f32
                 del out32
             except Exception as exc:             # never let the extras break the headline line

@@ -33,7 +33,10 @@ KEYS = {"jsd_lut_rows_kernel<double, 16>": ("JSD_n50000_d256", 256), "gram_i8_ti
         "gram_tile_kernel<0, double>": ("Eucl_f64_n50000_d256", 256), "pairdot_tile_kernel<1, 0, double>": ("KT_n50000_d256", 256),
         "pairdot_tile_kernel<1, 1, double>": ("BC_n50000_d4096", 4096), "valu_tile_kernel<1, double, 4>": ("JSD_ragged_n50000_d256", 256),
         "valu_tile_kernel<3, double, 8>": ("BC_ragged_n50000_d256", 256), "gram_i8_tile_kernel<2, 0, double>": ("Eucl_ragged_n50000_d256", 256),
-        "bc_sad_tile_kernel<double>": ("BC_sad_n50000", 4096), "gram_i8_tile_kernel<2, 4, double>": ("SC_n50000_d256", 256)}
+        "bc_sad_tile_kernel<double>": ("BC_sad_n50000", 4096), "gram_i8_tile_kernel<2, 4, double>": ("SC_n50000_d256", 256),
+        # float32 matrices (round 5): 8 bytes of output per pair
+        "gram_i8_quad_kernel<0>": ("Eucl_f32_n50000_d256", 256, 8.0), "gram_i8_stream_kernel<2, 0>": ("Eucl_f32_ragged_n50000_d256", 256, 8.0),
+        "gram_i8_stream_kernel<2, 4>": ("SC_f32_n50000_d256", 256, 8.0), "bc_sad_tile_kernel<float>": ("BC_sad_f32_n50000_d256", 256, 8.0)}
 _ver, _hash = lib_identity()
 out = {"_detail": {"how": __doc__.split("usage:")[0].strip(), "source": sys.argv[2], "lib_version": _ver, "src_hash": _hash}}
 print("%-46s %14s %16s %14s %14s %8s" % ("kernel (largest dispatch)", "FETCH_SIZE KiB", "fetch B (x2)", "WRITE_SIZE KiB", "traffic B", "/ algo"))
@@ -43,8 +46,8 @@ for k, v in sorted(vals.items(), key=lambda kv: -(kv[1].get("WRITE_SIZE", 0) + k
     fetch, write = 2.0 * v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
     ratio = ""
     if k in KEYS:
-        key, dim = KEYS[k]
-        algo = (16.0 + 2.0 * dim * 4.0 / (N - 1)) * PAIRS
+        key, dim = KEYS[k][:2]
+        algo = ((KEYS[k][2] if len(KEYS[k]) > 2 else 16.0) + 2.0 * dim * 4.0 / (N - 1)) * PAIRS
         ratio = "%.3f" % ((fetch + write) / algo)
         out[key] = fetch + write
         if key == "JSD_ragged_n50000_d256":      # the same kernel owns every tile of bench.py's uniform assembly under table_path=False

@@ -22,10 +22,13 @@ def profiles(pattern, seed, ragged=False):      # (ragged=True: lengths 1.5 - 2.
     return ctx.count_profiles(dseq, doff, pattern, "both")
 
 
+out32 = torch.empty((n, n), dtype=torch.float32, device="cuda")  # the container / multi-GPU CLI type (round 5)
 c, t = profiles("1111", 50001)
 for metric in ("JSD", "Eucl", "BC", "SC", "KT"):
     ctx.pairwise(c, t, metric, out=out)
 ctx.pairwise(c, t, "Eucl", out=out, table_path=False)          # float64 MFMA Gram
+for metric in ("Eucl", "SC", "BC"):                             # float32: gram_i8_quad_kernel, gram_i8_stream_kernel<2, SC>, bc_sad_tile_kernel<float>
+    ctx.pairwise(c, t, metric, out=out32, dtype="float32")
 # the ragged, dirty assembly of bench.py's config.ragged_assembly and tests/test_gpu_full_size.py (every tile a mixed tile)
 rseq, roff = synthetic.ragged_assembly(n, seed=2024)
 c, t = ctx.count_profiles(torch.from_numpy(rseq).cuda(), torch.from_numpy(roff.astype(np.int64)).cuda(), "1111", "both")
@@ -33,6 +36,7 @@ del rseq
 ctx.pairwise(c, t, "JSD", out=out)                                # general JSD kernel
 ctx.pairwise(c, t, "BC", out=out)                                 # general BC kernel
 ctx.pairwise(c, t, "Eucl", out=out)                               # two digit planes
+ctx.pairwise(c, t, "Eucl", out=out32, dtype="float32")            # two digit planes, float32: gram_i8_stream_kernel<2, Eucl>
 c, t = profiles("11011011", 50005)
 ctx.pairwise(c, t, "BC", out=out)                                 # C5: thermometer planes on the matrix cores
 ctx.pairwise(c, t, "BC", out=out, pairdot=False)                  # C5 through the packed-byte SAD kernel
