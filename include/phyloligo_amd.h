@@ -185,7 +185,14 @@ int po_count_byte_ranges_dev(po_ctx* ctx, const uint8_t* d_seq, uint64_t total_b
  * Computes rows [row_begin,row_end) x all n columns:
  *     out[(i-row_begin)*ld_out + j]   0 <= j < n,   ld_out >= n  (elements, not bytes)
  * Diagonal as the reference produces it: Eucl/JSD/BC/SC 0, KT 1 (0 for a constant row).
- * Row blocks are independent, which is how the matrix shards over GPUs (one context each).   */
+ * Row blocks are independent, which is how the matrix shards over GPUs (one context each).
+ * Layout of a DEVICE result and speed: any ld_out >= n is correct.  Rows that start on 16-byte boundaries (d_out 16-byte aligned and
+ * ld_out a multiple of 4 float32 / 2 float64 entries) leave as 16-byte stores; rows on whole 128-byte lines (ld_out a multiple of 32
+ * float32 / 16 float64 entries) are written ~25 % faster still, and an odd float32 leading dimension costs about 2 x (every 512-byte
+ * row piece of a tile then begins and ends inside a 32-byte sector that a neighbouring tile also writes).  The host-pointer forms
+ * below keep their device copy of the result on 128-byte rows whatever n is.  The metric of the largest matrices here, Eucl on the
+ * exact int8 path, makes ONE host synchronisation per call from 8 192 records on (it reads 4 bytes per 128 records back to deal the
+ * tiles to the kernels of their class); JSD and BC make one for the fold decision, as before.                                        */
 int po_pairwise(po_ctx* ctx, const uint32_t* counts, const uint64_t* totals, uint64_t n, uint32_t dim,
                 int metric, uint64_t row_begin, uint64_t row_end, int out_dtype, void* out, uint64_t ld_out,
                 uint32_t flags, po_stats* stats);

@@ -499,6 +499,16 @@ __global__ __launch_bounds__(kQuadThreads, 4) void gram_i8_quad_kernel(po_tile_a
     list_tile(A, tiles, blockIdx.x, ti, tj);
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
 
+    // the per-record terms of the epilogue come by LDS-DMA with the first staging step (their part of the LDS lies behind the
+    // scratch, outside the staging area): a global load behind the matrix-core loop would be waited for in the open
+    double* terms = reinterpret_cast<double*>(smem + kQuadScratchBytes);    // [t0 rows | t0 cols | t1 rows | t1 cols | t2 rows | t2 cols]
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t idx = wave * 2 + u, a = idx >> 1, side = idx & 1;   // six (Eucl) or two (SC) one-KiB instructions
+        if (idx < (METRIC == PO_EUCL ? 6u : 2u))
+            po_glds16(rs + a * A.npad + (side ? j0 : i0) + 2 * lane, reinterpret_cast<unsigned char*>(terms + a * 256 + side * 128));
+    }
+
     v16i g[2][1][2];                                       // [row block bi][plane sum][column block]
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi)
@@ -535,15 +545,8 @@ __global__ __launch_bounds__(kQuadThreads, 4) void gram_i8_quad_kernel(po_tile_a
     // (lane coordinates derived again: anything per-lane that lives across the matrix-core loop is spilled at the register limit)
     uint32_t lane_e;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
-    const uint32_t t_e = wave * 64u + lane_e, lr_e = lane_e & 31, lh_e = lane_e >> 5;
+    const uint32_t lr_e = lane_e & 31, lh_e = lane_e >> 5;
     float* tl = reinterpret_cast<float*>(smem);
-    double* terms = reinterpret_cast<double*>(smem + kQuadScratchBytes);
-    {
-        const uint64_t rec = (t_e < 128) ? i0 + t_e : j0 + (t_e - 128);
-        terms[t_e] = rs[rec];
-        terms[256 + t_e] = METRIC == PO_EUCL ? rs[A.npad + rec] : 0.0;
-        terms[512 + t_e] = METRIC == PO_EUCL ? rs[2 * A.npad + rec] : 0.0;
-    }
     const bool mirror = po_tile_mirrors(A, ti, tj);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
