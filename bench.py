@@ -349,10 +349,13 @@ def main():
     d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
     ctx.count_profiles(d_seq, d_off, args.pattern, "both")          # untimed first call (allocations)
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    my_counts, my_totals = ctx.count_profiles(d_seq, d_off, args.pattern, "both")
-    torch.cuda.synchronize(dev)
-    stage1_ms = (time.perf_counter() - t0) * 1e3
+    stage1_ms = None
+    for _ in range(3):                                               # best of 3, like every other line of the record
+        t0 = time.perf_counter()
+        my_counts, my_totals = ctx.count_profiles(d_seq, d_off, args.pattern, "both")
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) * 1e3
+        stage1_ms = dt if stage1_ms is None else min(stage1_ms, dt)
     allgather_ms = None
     if dist is not None:
         dist.barrier()
@@ -639,10 +642,13 @@ def main():
                 d_roff = torch.from_numpy(roff.astype(np.int64)).to(dev)
                 ctx.count_profiles(d_rseq, d_roff, args.pattern, "both")
                 torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-                rc_, rt_ = ctx.count_profiles(d_rseq, d_roff, args.pattern, "both")
-                torch.cuda.synchronize(dev)
-                r_stage1 = (time.perf_counter() - t0) * 1e3
+                r_stage1 = None
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    rc_, rt_ = ctx.count_profiles(d_rseq, d_roff, args.pattern, "both")
+                    torch.cuda.synchronize(dev)
+                    dt = (time.perf_counter() - t0) * 1e3
+                    r_stage1 = dt if r_stage1 is None else min(r_stage1, dt)
                 rdim = rc_.shape[1]
                 rbpp = 16 + 2 * rdim * 4 / (n - 1)
                 rag = {"workload": "%d contigs, log-normal lengths 1 - 200 kb (%.3f Gb, longest %d), base compositions %s by i %% 4, N runs, "
@@ -651,7 +657,7 @@ def main():
                        "generate_s": gen_s, "bases": int(rseq.size), "largest_count": int(rc_.max()),
                        "stage1_ms": r_stage1,
                        "stage1_roofline": hbm_roofline(rseq.size + n * rdim * 4 + n * 8, r_stage1,
-                                                       note="wall time of po_count_profiles_dev (scan + memset + count_kernel), algorithmic "
+                                                       note="wall time of po_count_profiles_dev (scan, row zeroing, count_kernel, segment sums; best of 3), algorithmic "
                                                             "bytes = bases + counts + totals (SURVEY 8d)"),
                        "metrics": {}}
                 del d_rseq
