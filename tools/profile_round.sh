@@ -4,7 +4,7 @@
 #   2. separate --pmc passes (no trace domains mixed in) over tools/pmc_workload.py: busy figures of every tile kernel
 #   3. FETCH_SIZE / WRITE_SIZE passes (separate) over tools/pmc_workload.py: HBM-side traffic of every tile kernel -> traffic.json
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-tag=${1:-r04}; out=gpurun_out/prof_$tag; mkdir -p $out
+tag=${1:-r05}; out=gpurun_out/prof_$tag; mkdir -p $out
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $out/stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench.json 2> $out/bench.err || echo "stats pass failed"
 python3 tools/rocpd_summary.py $out/stats > $out/${tag}_bench_kernel_stats.txt 2>&1
 i=0
