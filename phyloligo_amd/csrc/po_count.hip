@@ -495,7 +495,13 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
             bad = __builtin_amdgcn_bitop3_b32(bad, w[j] & 0xDFDFDFDFu, __builtin_amdgcn_perm(0u, 0x47544341u, code), 0xF6);
             dg[j] = __builtin_amdgcn_perm(0u, 0x01030002u, code);                  // C0 G1 A2 T3
         }
-        if (!__any((int)(bad != 0u))) {
+        // Round 5: a byte that is not A/C/G/T somewhere in the 2 048 no longer sends the whole chunk to the general path (three
+        // times the instructions: 17 % of the chunks of a real assembly - N runs, IUPAC codes - cost as much as the other 83 %).
+        // A window counts iff none of its W bases is such a byte; the fast path already adds "the start's bit of the lane's
+        // validity mask", so all it takes is clearing the bits of the starts whose window touches one (dirty_starts below) and
+        // counting the words that remain instead of computing their number.
+        const bool dirty = __any((int)(bad != 0u));
+        {
             // 16 digit bytes -> 32 bits, first base lowest
             auto pack16 = [](uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) -> uint32_t {
                 const uint32_t t0 = d0 | (d0 >> 6), t1 = d1 | (d1 >> 6), t2 = d2 | (d2 >> 6), t3 = d3 | (d3 >> 6);   // bytes 0, 2: two digits
@@ -508,12 +514,39 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
             // starts that count, in staged coordinates: [st_lo, st_hi) (wave uniform), this lane's part as a bit mask
             const int32_t st_lo = (int32_t)(p_lo - pos0);
             const int32_t st_hi = max(st_lo, (int32_t)(min(p_hi, L - (int64_t)W + 1) - pos0));
-            uni_count += (uint32_t)(st_hi - st_lo) * (MODE == 2 ? 2u : per_word);
             const int32_t s_lo = max(st_lo - (int32_t)(lane * kPerLane), 0);
             const int32_t s_hi = min(st_hi - (int32_t)(lane * kPerLane), (int32_t)kPerLane);
+            uint32_t vmask = 0;
             if (s_hi > s_lo) {
                 const uint32_t span = (uint32_t)(s_hi - s_lo);
-                const uint32_t vmask = (span >= 32u ? 0xFFFFFFFFu : ((1u << span) - 1u)) << s_lo;
+                vmask = (span >= 32u ? 0xFFFFFFFFu : ((1u << span) - 1u)) << s_lo;
+            }
+            uint32_t badcode[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // 0x04 in the byte of every base that is not A/C/G/T (dirty chunks)
+            if (!dirty) {
+                uni_count += (uint32_t)(st_hi - st_lo) * (MODE == 2 ? 2u : per_word);
+            } else {
+                uint32_t bm = 0;                                    // bit i: base i of this lane's 32 is not A/C/G/T
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t code = (w[j] >> 1) & 0x03030303u;
+                    const uint32_t mism = (w[j] & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, code);
+                    const uint32_t hb = (((mism & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | mism) & 0x80808080u;   // top bit of every non-zero byte
+                    badcode[j] = hb >> 5;
+                    bm |= (((hb >> 7) * 0x10204080u) >> 28) << (4 * j);                              // those four bits side by side
+                }
+                const uint32_t nbm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bm, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+                unsigned long long touched = (unsigned long long)bm | ((unsigned long long)nbm << 32);
+                for (uint32_t covered = 1; covered < W;) {           // OR of (touched >> i) for i < W, by doubling (W is wave uniform)
+                    const uint32_t step = min(covered, W - covered);
+                    touched |= touched >> step;
+                    covered += step;
+                }
+                vmask &= ~(uint32_t)touched;                        // dirty_starts cleared
+                uint32_t words = (uint32_t)__popc(vmask);
+                for (int o = 32; o > 0; o >>= 1) words += __shfl_down(words, o, 64);
+                uni_count += (uint32_t)__builtin_amdgcn_readfirstlane((int)words) * (MODE == 2 ? 2u : per_word);
+            }
+            if (vmask != 0u) {
                 if (RUNS < 0) {
                     const uint32_t m4 = (P.dim - 1u) << 2;
                     uint32_t hbase;                                 // in a vector register: v_and_or_b32 takes one scalar operand
@@ -538,7 +571,7 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
             // junction windows of seq + revcomp(seq) (symmetric mode; see the general code below for the pairing rule)
             if (P.strand == PO_STRAND_BOTH && p_hi == L && W > 1) {
                 const int64_t ts64 = L - (int64_t)W + 1 - pos0;     // staged index of the first of the record's last W-1 bases
-                if (ts64 >= 0 && L >= (int64_t)W - 1) {           // the W-1 bases exist and are staged
+                if (!dirty && ts64 >= 0 && L >= (int64_t)W - 1) { // the W-1 bases exist, are staged (and are bases: a dirty chunk asks the general code)
                     const uint32_t st = (uint32_t)ts64 & 31u, lt = (uint32_t)ts64 >> 5;
                     const uint32_t sel = st < 16u ? __builtin_amdgcn_alignbit(phi, plo, 2u * st)
                                                   : __builtin_amdgcn_alignbit(halo, phi, 2u * st - 32u);
@@ -555,8 +588,8 @@ __global__ __launch_bounds__(1024) void count_kernel(const uint8_t* __restrict__
                     }
                     uni_count += MODE == 2 ? W - 1u : 2u * ((W - 1u) >> 1) + ((W & 1u) ? 0u : 1u);
                 } else {                                           // shorter record, or the tail starts before the staged range: general code below
-                    *reinterpret_cast<uint4*>(codes + lane * kPerLane) = make_uint4(dg[0], dg[1], dg[2], dg[3]);
-                    *reinterpret_cast<uint4*>(codes + lane * kPerLane + 16) = make_uint4(dg[4], dg[5], dg[6], dg[7]);
+                    *reinterpret_cast<uint4*>(codes + lane * kPerLane) = make_uint4(dg[0] | badcode[0], dg[1] | badcode[1], dg[2] | badcode[2], dg[3] | badcode[3]);
+                    *reinterpret_cast<uint4*>(codes + lane * kPerLane + 16) = make_uint4(dg[4] | badcode[4], dg[5] | badcode[5], dg[6] | badcode[6], dg[7] | badcode[7]);
                     slow_junction = true;
                 }
             }

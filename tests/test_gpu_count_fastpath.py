@@ -4,7 +4,8 @@ words) - bit-exact against the oracle (pinned by the goldens to the reference's 
 select_strand, /root/reference/phylopackage/bin/phyloligo.py:124-149, :601-631) on the cases its index arithmetic can
 get wrong: record lengths around the 32-base lane, the 2 016-start chunk and the window length, records that start at
 every alignment, the chunk whose tail lies before the staged range, the last record of the buffer, lower case, and
-clean records next to dirty ones (which take the general path inside the same launch)."""
+clean records next to dirty ones (which took the general path inside the same launch until round 5 and stay on the fast path
+since: test_dirty_chunks_on_the_fast_path)."""
 import numpy as np
 import pytest
 
@@ -72,6 +73,35 @@ def test_clean_and_dirty_neighbours(ctx, seed):
             r[int(rng.integers(0, n))] = ord("N")
         records.append(bytes(r))
     check(ctx, records, pattern, strands=("both", "plus", "minus"))
+
+
+@pytest.mark.parametrize("pattern", PATTERNS)
+def test_dirty_chunks_on_the_fast_path(ctx, pattern):
+    """Round 5: a chunk with bytes that are not A/C/G/T stays on the fast path - the starts whose window touches such a byte
+    are cleared from the lanes' validity masks (the touched bits cross lanes with the register string's halo), the words are
+    counted instead of computed, and the junction windows of `-s both` go through the per-base code.  Dirt where that can go
+    wrong: the first and the last base of a record, inside its last W - 1 bases (the junction), around the 32-base lane, around
+    the 2 016-start chunk, runs longer than the window, IUPAC codes and lower-case n, a record that is nothing but dirt."""
+    rng = np.random.default_rng(len(pattern) * 31 + pattern.count("1"))
+    W = len(pattern)
+    records = []
+    for n in (1, 2, W - 1, W, W + 1, 2 * W, 31, 32, 33, 64, 65, 100, 2000, 2015, 2016, 2017, 2048, 4031, 4033, 6049, 9000):
+        if n < 1:
+            continue
+        spots = {0, n - 1, n // 2, max(0, n - W), max(0, n - W + 1), max(0, n - 2), min(n - 1, 31), min(n - 1, 32), min(n - 1, 33),
+                 min(n - 1, 63), min(n - 1, 64), min(n - 1, 2015), min(n - 1, 2016), min(n - 1, 2017), min(n - 1, 2047), min(n - 1, 2048)}
+        for k, spot in enumerate(sorted(min(max(x, 0), n - 1) for x in spots)):
+            if k % 3 != int(rng.integers(0, 3)):
+                continue
+            r = bytearray(clean(rng, n, lower=rng.random() < 0.3))
+            r[spot] = ord(str(rng.choice(list("NnRYKMSWBDHVU-*"))))
+            if rng.random() < 0.4:                                  # a run that is longer than the window, somewhere else
+                a = int(rng.integers(0, n))
+                r[a:a + W + 3] = b"N" * len(r[a:a + W + 3])
+            records.append(bytes(r))
+    records += [b"N" * 40, b"NNNN", bytes(clean(rng, 2500)), b"n" * 2100, b"ACGT" * 3 + b"R" + b"ACGT" * 600]
+    order = rng.permutation(len(records))
+    check(ctx, [records[i] for i in order], pattern, strands=("both", "plus", "minus"))
 
 
 def test_long_record_and_windows(ctx):
