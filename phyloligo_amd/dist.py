@@ -218,7 +218,10 @@ class RowBlockPlan:
             ops, placed = [], []
             for m, peer, per, nch in sends:
                 if k < nch:
-                    ops.append(dist.P2POp(dist.isend, m[k * per:min(m.shape[0], (k + 1) * per)], peer))
+                    piece = m[k * per:min(m.shape[0], (k + 1) * per)]
+                    # (mirror buffers keep their rows on 128-byte boundaries: a block whose width is not a multiple of 32 is a
+                    #  strided view, and a message has to be contiguous - one packed copy of the chunk, <= chunk_bytes)
+                    ops.append(dist.P2POp(dist.isend, piece if piece.is_contiguous() else piece.contiguous(), peer))
             for stage, src, per, nch, a0, a1, b0, b1 in recvs:
                 if k < nch:
                     rows = min(a1 - a0, (k + 1) * per) - k * per

@@ -57,11 +57,15 @@ def _exchange_worker(rank, world, port, n, chunk_bytes, ret):
         m = rng.random((n, n))
         full = torch.from_numpy(m + m.T)                      # the symmetric matrix the kernels would produce
         lo, hi = plan.rows(rank)
-        slab = torch.full((hi - lo, n), float("nan"), dtype=torch.float64)
-        mirrors = []
-        for (r0, r1), (c0, c1), kind, peer in plan.work(rank):   # stand-in for plan.compute()
+        # the plan's own buffers: rows on 128-byte boundaries, i.e. strided views whenever a width is not a multiple of 32 entries
+        # (n = 100, 131 and the 16-aligned blocks here) - the exchange has to cope with them (round 5)
+        slab, mirrors = plan.allocate(rank, "cpu", torch.float64)
+        slab.fill_(float("nan"))
+        assert slab.shape == (hi - lo, n) and (n % 32 == 0 or hi - lo < 2 or not slab.is_contiguous())
+        for ((r0, r1), (c0, c1), kind, peer), mir in zip(plan.work(rank), mirrors):   # stand-in for plan.compute()
             slab[r0 - lo:r1 - lo, c0:c1] = full[r0:r1, c0:c1]
-            mirrors.append(None if kind == "diag" else full[r0:r1, c0:c1].T.contiguous())
+            if kind != "diag":
+                mir.copy_(full[r0:r1, c0:c1].T)
         plan.complete_rows(rank, slab, mirrors, dist, chunk_bytes=chunk_bytes)
         ret[rank] = bool(torch.equal(slab, full[lo:hi]))
     finally:
