@@ -216,6 +216,18 @@ static int fold_plan(po_ctx* ctx, uint32_t dim, uint32_t gran, uint32_t* dim_f, 
     const uint32_t ppad = selfs_first ? (uint32_t)selfs.size() : (uint32_t)po_round_up(pairs.size(), gran);
     const uint32_t spad = selfs_first ? (uint32_t)(po_round_up(selfs.size() + pairs.size(), 16) - selfs.size())
                                       : (uint32_t)po_round_up(selfs.size(), 8);
+    // A folded matrix that is WIDER than the input is no use - and the workspaces of the JSD / Bray-Curtis path are sized for the
+    // input's width: at k = 1, 2 the padding of the two regions (Bray-Curtis: 32 + 8 words for 6 + 4 at k = 2) made the "folded"
+    // matrix 2.5 x as wide as the 16 words it came from, and the operands built from it ran past buffers sized for 16 - silently
+    // on small inputs, a memory fault at 8 191 records (found by a size sweep in round 5; present since round 1).  Not folded.
+    // (The Kendall layout is consumed through its source table only, word pair by word pair: it folds at every k.)
+    if (!selfs_first && ppad + spad > dim) {
+        ctx->fold_dim = dim;
+        ctx->fold_gran = gran;
+        ctx->fold_dim_f = 0;
+        ctx->fold_dbl_at = 0xFFFFFFFFu;
+        return PO_OK;
+    }
     std::vector<uint32_t> src(ppad + spad, 0xFFFFFFFFu);
     if (selfs_first) std::swap(pairs, selfs);            // first region: self-paired words, second: representatives
     for (size_t i = 0; i < pairs.size(); ++i) src[i] = pairs[i];

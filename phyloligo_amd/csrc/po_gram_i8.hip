@@ -750,7 +750,9 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
     }
     // (three planes: five accumulator groups = 160 registers of the 168 a wave of a nine-wave workgroup may have - those tiles, the
     //  few that hold a record of more than ~1 Mb, stay with the tile kernel and its float32 tile epilogue)
-    if constexpr (P == 2) if (a.out_f32) {
+    // (word spaces of more than 512 words - k >= 5 - are bound by the matrix cores, not by the epilogue: there two eight-wave
+    //  workgroups per CU beat the one persistent workgroup, k = 6 Spearman 4.15 against 4.66 ms at 20 000 records)
+    if constexpr (P == 2) if (a.out_f32 && dpad <= 512) {
         // one persistent workgroup per CU (a multiple of the 8 XCDs, so that a workgroup's tiles stay on its XCD's range)
         auto k = gram_i8_stream_kernel<P, METRIC>;
         PO_SHMEM(ctx, k, (size_t)stream_cfg<P>::lds_bytes);
@@ -762,7 +764,7 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
         return PO_OK;
     }
     if (a.out_f32) {
-        if constexpr (P == 3) {                            // (one and two planes returned above)
+        if constexpr (P >= 2) {                            // (one plane - and two planes up to 512 words - returned above)
             auto k = gram_i8_tile_kernel<P, METRIC, float>;
             PO_SHMEM(ctx, k, shmem);
             hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);

@@ -65,7 +65,11 @@ def test_both_strands_palindromic_pattern_folds(ctx, pattern, metric):
     assert np.array_equal(counts, counts[:, rc_index(counts.shape[1])])        # the symmetry the fold relies on
     folded, st = ctx.pairwise(counts, totals, metric, want_stats=True)
     plain, st0 = ctx.pairwise(counts, totals, metric, want_stats=True, rc_fold=False)
-    assert st["rc_folded"] and not st0["rc_folded"]
+    # (k = 1, and k = 2 for Bray-Curtis: the padded folded layout would be WIDER than the 4 / 16 words it stands for - not
+    #  folded, round 5; JSD at k = 2 folds into the same 16 words)
+    k_ = pattern.count("1")
+    folds = k_ >= 3 or (k_ == 2 and metric == "JSD")
+    assert bool(st["rc_folded"]) == folds and not st0["rc_folded"]
     np.testing.assert_allclose(folded, plain, rtol=1e-9, atol=2e-11, equal_nan=True)
     assert np.array_equal(np.isnan(folded), np.isnan(plain))
     freq = oracle.counts_to_frequencies(counts.astype(np.int64), totals.astype(np.int64))
@@ -84,7 +88,7 @@ def test_both_strands_palindromic_pattern_folds(ctx, pattern, metric):
     f32 = ctx.pairwise(counts, totals, metric, dtype="float32")
     np.testing.assert_allclose(f32, plain.astype(np.float32), rtol=1e-6, atol=1e-7, equal_nan=True)
     gf, stf = ctx.pairwise_freq(ctx.frequencies(counts, totals), metric, want_stats=True)
-    assert stf["rc_folded"]
+    assert bool(stf["rc_folded"]) == folds
     np.testing.assert_allclose(gf, plain, rtol=1e-9, atol=2e-11, equal_nan=True)
 
 
@@ -223,3 +227,28 @@ def test_kendall_panel_kernel_large_word_spaces(ctx, pattern, strand, expect_fol
     sub = ctx.pairwise(counts, totals, "KT", row_begin=5, row_end=133 if n > 133 else n - 3)
     assert np.array_equal(sub, got[5:133 if n > 133 else n - 3], equal_nan=True)
     assert np.array_equal(got, got.T, equal_nan=True) and np.all(np.diag(got)[totals > 0] == 1.0)
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_word_spaces_whose_folded_layout_would_be_wider_are_not_folded(ctx, k):
+    """Round 5, found by a size sweep (tools/exp/f32_regime_sweep.py): at k = 1, 2 the two zero-padded regions of the folded layout
+    (Bray-Curtis: 32 + 8 words for the 6 + 4 orbits of k = 2) are WIDER than the 4 / 16 words they stand for, and every workspace of
+    the call is sized for the input's width - the operands built from the "folded" matrix ran past their buffers: silently on small
+    inputs, a memory fault at 8 191 records (since round 1).  Such word spaces are no longer folded.  8 191 strand-symmetric
+    records of 2 kb (counts beyond 255 at k = 2: the general Bray-Curtis kernel, which is the one that faulted), all five metrics,
+    against the oracle on sampled rows and against rc_fold=False on the whole matrix."""
+    n = 8191
+    seq, off = synthetic.contig_bytes(n, 2000, seed=77)
+    counts, totals = ctx.count_profiles(seq, off, "1" * k, "both")
+    freq = oracle.counts_to_frequencies(counts.astype(np.int64), totals.astype(np.int64))
+    rows = [0, 1, 4095, 8190]
+    for metric in ("BC", "JSD", "KT", "Eucl", "SC"):
+        got, st = ctx.pairwise(counts, totals, metric, want_stats=True)
+        assert bool(st["rc_folded"]) == (metric == "KT" or (metric == "JSD" and k == 2)), metric   # Kendall folds through its source table
+        plain = ctx.pairwise(counts, totals, metric, rc_fold=False)
+        if st["rc_folded"] and metric == "JSD":                # (folded float64 sums: another order of summation)
+            np.testing.assert_allclose(got, plain, rtol=1e-9, atol=2e-11, equal_nan=True)
+        else:
+            assert np.array_equal(got, plain, equal_nan=True), metric
+        want = oracle.pairwise_rows(freq, metric, rows)
+        np.testing.assert_allclose(got[rows], want, rtol=RTOL, atol=1e-9 if metric in ("SC", "KT") else ATOL, equal_nan=True, err_msg=metric)
