@@ -261,8 +261,9 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const uint64_t* __restr
 // the state buffer belongs to this kernel alone and entries of earlier calls can never be mistaken for this call's, so nothing
 // is cleared between calls; the workgroup with the last ticket - which has seen every aggregate - writes the grand total and the
 // largest record and hands the ticket counter back at zero.  The word totals of the records are zeroed on the way (one memset
-// less).  Up to kOnePassBlocks workgroups (4 M records); beyond that the three launches above.
-constexpr uint32_t kOnePassBlocks = 4096;
+// less).  Up to kOnePassBlocks workgroups (1 M records: every workgroup reads all aggregates before its own, which is quadratic -
+// at 4 096 workgroups of tiny records the three launches above were faster, 3.3 against 4.6 ms); beyond that the three launches.
+constexpr uint32_t kOnePassBlocks = 1024;
 __global__ __launch_bounds__(256) void scan_chunks_kernel(const uint64_t* __restrict__ begins, const uint64_t* __restrict__ ends, uint32_t n,
                                                           uint32_t nb, unsigned long long* __restrict__ agg, unsigned long long* __restrict__ big,
                                                           uint32_t* __restrict__ ticket, uint32_t* __restrict__ empty_tag, uint32_t epoch,
