@@ -203,7 +203,7 @@ __device__ __forceinline__ double gram_i8_value(const double G, const double t0r
 // result is set where gram_i8_value has to be asked instead - a squared distance at cancellation level (or exactly 0: the square
 // root below has no zero guard), identical rank vectors.  A branch per pair keeps every pair's ~20 dependent float64
 // instructions in a basic block of their own; written like this, N independent chains are in flight in one wave, which is what
-// two waves per SIMD need to keep the vector ALU busy (gram_i8_stream_kernel).  Where its bit is clear a result equals
+// two waves per SIMD need to keep the vector ALU busy (the persistent variant of round 5, and any kernel at low occupancy).  Where its bit is clear a result equals
 // gram_i8_value's bit for bit.
 template <int METRIC, int N>
 __device__ __forceinline__ uint32_t gram_i8_values_fast(const double (&G)[N], const double (&t0r)[N], const double (&t1r)[N],
@@ -250,15 +250,17 @@ __device__ __forceinline__ uint32_t gram_i8_values_fast(const double (&G)[N], co
 // 64 wc .. - from its accumulators into the float32 tile scratch `tl` (po_tiles.h).  Accumulator layout (32x32): column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  kIlpRows rows
 // = 2 kIlpRows pairs are in flight at a time (every pair holds ~10 registers); the rare cases follow wave by wave.
 // terms: [t0 rows | t0 cols | t1 rows | t1 cols | t2 rows | t2 cols] of the tile's 128 + 128 records (LDS).
-template <int P, int METRIC, int kIlpRows>
+template <int P, int METRIC, int kIlpRows, int STRIDE = kF32TileStride>
 __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1][2], const double* terms, const uint32_t rrow,
                                                        const uint32_t trow, const uint32_t wc, const uint32_t lr, const uint32_t lh,
-                                                       const bool diag_tile, float* tl) {
+                                                       const bool diag_tile, float* tl, const uint32_t ccol_of_block = 0xFFFFFFFFu) {
     constexpr int NG = 2 * P - 1;
+    // the block's first column inside the tile (for the diagonal of the matrix): 64 wc, unless the scratch is a column half of the tile
+    const uint32_t ccol = ccol_of_block == 0xFFFFFFFFu ? wc * 64 : ccol_of_block;
     const double* t0r = terms + rrow, *t0c = terms + 128 + wc * 64;             // Eucl: S/n^2      SC: N
     const double* t1r = terms + 256 + rrow, *t1c = terms + 384 + wc * 64;       // Eucl: 1/n
     const double* t2r = terms + 512 + rrow, *t2c = terms + 640 + wc * 64;       // Eucl: S
-    float* wt = tl + (trow + 4 * lh) * kF32TileStride + wc * 64 + lr;
+    float* wt = tl + (trow + 4 * lh) * STRIDE + wc * 64 + lr;
     const double tc0 = t0c[lr], tc1 = t0c[32 + lr];
     const double ic0 = METRIC == PO_EUCL ? t1c[lr] : 0.0, ic1 = METRIC == PO_EUCL ? t1c[32 + lr] : 0.0;
     auto gram = [&](const int nn, const int reg) -> double {
@@ -283,10 +285,11 @@ __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1
             b1[2 * e] = ic0; b1[2 * e + 1] = ic1;
         }
         special |= gram_i8_values_fast<METRIC, 2 * kIlpRows>(G, a0, a1, b0, b1, v);
+        asm volatile("" : "+v"(special));                  // one running word, not sixteen partial ones kept for a tree of ORs
 #pragma unroll
         for (int e = 0; e < kIlpRows; ++e) {
             const int reg = r0 + e;
-            float* wp = wt + ((reg & 3) + 8 * (reg >> 2)) * kF32TileStride;
+            float* wp = wt + ((reg & 3) + 8 * (reg >> 2)) * STRIDE;
             wp[0] = v[2 * e];
             wp[32] = v[2 * e + 1];
         }
@@ -311,9 +314,9 @@ __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1
         for (int reg = 0; reg < 16; ++reg) {
             const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             const double trr = t0r[rl], irr = METRIC == PO_EUCL ? t1r[rl] : 0.0;
-            float* wp = wt + ((reg & 3) + 8 * (reg >> 2)) * kF32TileStride;
-            wp[0] = (float)gram_i8_value<METRIC>(gram_again(0, reg), trr, irr, t2r + rl, tc0, ic0, t2c + lr, diag_tile && rrow + rl == wc * 64 + lr);
-            wp[32] = (float)gram_i8_value<METRIC>(gram_again(1, reg), trr, irr, t2r + rl, tc1, ic1, t2c + 32 + lr, diag_tile && rrow + rl == wc * 64 + 32 + lr);
+            float* wp = wt + ((reg & 3) + 8 * (reg >> 2)) * STRIDE;
+            wp[0] = (float)gram_i8_value<METRIC>(gram_again(0, reg), trr, irr, t2r + rl, tc0, ic0, t2c + lr, diag_tile && rrow + rl == ccol + lr);
+            wp[32] = (float)gram_i8_value<METRIC>(gram_again(1, reg), trr, irr, t2r + rl, tc1, ic1, t2c + 32 + lr, diag_tile && rrow + rl == ccol + 32 + lr);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -561,175 +564,112 @@ __global__ __launch_bounds__(kQuadThreads, 4) void gram_i8_quad_kernel(po_tile_a
     }
 }
 
-// ---- float32 output: one persistent workgroup per CU, a loader wave, stores that are never waited for (round 5) ----------
-// With a float32 matrix the tile kernel above has as much float64 arithmetic per byte stored as store time: isolating builds at
-// 200 000 records (160 GB) take 23.6 ms without the global stores and 28.4 ms without the distance arithmetic, the kernel 38.5 -
-// the two phases of a workgroup follow each other, and only the other workgroup of the CU overlaps them.  A wave cannot run
-// ahead of its own stores either: on gfx9 loads and stores share the in-order vmcnt counter, so the wait for the next tile's
-// operands is a wait for every store issued before them.  Here the waves that store never load:
-//   * kStreamWaves computing waves (the 4 x 2 blocks of 32 x 64 pairs of the tile kernel) take tile after tile (virtual
-//     workgroup indices blockIdx.x, + gridDim.x, ...: the XCD-banded order of po_tiles.h is kept, the 32 workgroups of an XCD
-//     work on 32 consecutive tiles of its range).  Operands reach them through LDS only, their vector-memory instructions are
-//     the output stores alone, and nothing ever waits for those: the stores of tile k drain under the matrix-core and
-//     float64 work of tile k + 1.
-//   * one loader wave stages the operands - a ring of two staging steps, KCH bytes of K per record and step - and the
-//     per-record terms of the NEXT tile by LDS-DMA; its vmcnt holds loads only.
-//   * hand-over by s_barrier (all kStreamWaves + 1 waves, the same sequence for every wave): barrier b_g says "step g has landed
-//     and step g - 1 has been consumed" (so the loader may refill that slot), barrier E1 after a tile's values are in the
-//     float32 tile scratch says "the scratch is complete, and the terms buffer and the last slot are free".  The scratch is read
-//     (and the stores issued) between E1 and the next tile's b_0; it is written again only after that tile's matrix-core phase.
-// LDS: ring 2 x P x 2 x (KCH / 16) x 2 KiB (64 / 64 / 48 KiB for P = 1 / 2 / 3) + 65 KiB of scratch + 6 KiB of terms.
-constexpr int kStreamWaves = 8;
-constexpr int kStreamThreads = 64 * (kStreamWaves + 1);
-template <int P> struct stream_cfg {
-    static constexpr int kch = P == 1 ? 128 : (P == 2 ? 64 : 32);      // bytes of K per record and staging step
-    static constexpr int chunks = kch / 16;                            // 16-byte K-chunks per step
-    static constexpr int step_bytes = P * 2 * chunks * kChunkBytes;
-    static constexpr int ring_bytes = 2 * step_bytes;
-    static constexpr int lds_bytes = ring_bytes + kF32TileBytes + kTermBytes;
-};
+// ---- float32 output, two digit planes: four waves on HALF a tile (128 x 64 pairs), four workgroups per CU (round 5) --------
+// Two planes are three accumulator groups: 96 registers for a 32 x 64 wave block, which rules out the 64 x 64 blocks of the quad
+// kernel at four workgroups per CU.  Here a workgroup of four waves takes the left or the right half of a tile - wave w rows
+// 32 w .., all 64 columns of the half -, the operands arrive in steps of 64 bytes of K (24 KiB), the scratch holds the half
+// (128 x 64 float32, row stride 66: its rows leave as 256-byte pieces, its transposed rows as 512-byte pieces): 39 KiB of LDS, <= 128
+// registers, four workgroups per CU.  The two halves of a tile run on the same XCD one after the other (workgroup b: XCD b % 8, half
+// (b / 8) & 1), so the row operand they share is read from HBM once.
+constexpr int kHalfThreads = 256;
+constexpr int kHalfStride = 66;
+constexpr int kHalfKch = 64;                                           // bytes of K per record and staging step
+constexpr int kHalfStageA = 2 * (kHalfKch / 16) * kChunkBytes;         // [p][4 chunks][128 records][16 B] = 16 KiB
+constexpr int kHalfStageBytes = kHalfStageA + kHalfStageA / 2;         // + the same for the 64 column records
+constexpr int kHalfScratchBytes = 128 * kHalfStride * 4;               // 33 792 B, over the staging area
+constexpr int kHalfLdsBytes = kHalfScratchBytes + kTermBytes;
 
-template <int P, int METRIC>
-__global__ __launch_bounds__(kStreamThreads) void gram_i8_stream_kernel(po_tile_args A, const int8_t* __restrict__ planes,
-                                                                        uint32_t dpad, const double* __restrict__ rs,
-                                                                        const uint32_t* __restrict__ maxabs, long long run_above,
-                                                                        long long run_upto, tile_list tiles) {
+template <int METRIC>
+__global__ __launch_bounds__(kHalfThreads, 4) void gram_i8_half_kernel(po_tile_args A, const int8_t* __restrict__ planes, uint32_t dpad,
+                                                                       const double* __restrict__ rs, const uint32_t* __restrict__ maxabs,
+                                                                       long long run_above, long long run_upto, tile_list tiles) {
+    static_assert(kHalfStageBytes <= kHalfScratchBytes, "the scratch covers the staging area");
     if (maxabs != nullptr) {
         const long long m = *maxabs;
         if (m <= run_above || m > run_upto) return;
     }
-    using cfg = stream_cfg<P>;
-    const uint64_t nb = tiles.count;
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char* ring = smem;
-    float* tl = reinterpret_cast<float*>(smem + cfg::ring_bytes);
-    double* terms = reinterpret_cast<double*>(smem + cfg::ring_bytes + kF32TileBytes);   // [t0 rows | t0 cols | t1 rows | t1 cols | t2 rows | t2 cols]
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t steps = dpad / cfg::kch;                // staging steps per tile (dpad is a multiple of 128)
-    const size_t plane = (size_t)A.npad * dpad;
-    // which digit planes a tile needs (three-plane kernel: by the largest count of its two blocks of records, see above)
-    auto planes_of = [&](uint32_t ti, uint32_t tj, uint32_t& pr, uint32_t& pc) {
-        pr = P; pc = P;
-        if (P == 3 && maxabs != nullptr) {
-            const uint32_t mr = maxabs[1 + ti], mc = maxabs[1 + tj];
-            pr = mr <= 127u ? 1u : (mr <= 16383u ? 2u : 3u);
-            pc = mc <= 127u ? 1u : (mc <= 16383u ? 2u : 3u);
-        }
-    };
-
-    if (wave == kStreamWaves) {
-        // ================= the loader wave =================
-        struct tile_at { uint64_t i0, j0; uint32_t pr, pc; };
-        auto locate = [&](uint64_t w) {                                // the tile of virtual workgroup w and the planes it needs
-            uint32_t ti, tj;
-            tile_at t;
-            list_tile(A, tiles, w, ti, tj);
-            planes_of(ti, tj, t.pr, t.pc);
-            t.i0 = (uint64_t)ti * TM; t.j0 = (uint64_t)tj * TN;
-            return t;
-        };
-        auto stage = [&](const tile_at& t, uint32_t s, uint32_t slot) {   // step s of the tile into ring slot `slot`
-            unsigned char* dst = ring + slot * cfg::step_bytes;
-#pragma unroll
-            for (int idx = 0; idx < P * 2 * cfg::chunks * 2; ++idx) {  // one-KiB LDS-DMA instructions: [p][side][q][half]
-                const uint32_t half = idx & 1, q = (idx >> 1) % cfg::chunks, side = ((idx >> 1) / cfg::chunks) & 1, p = (idx >> 1) / (2 * cfg::chunks);
-                if (P == 3 && p >= (side ? t.pc : t.pr)) continue;     // a digit plane that is all zero for this block of records
-                const uint64_t rec = (side ? t.j0 : t.i0) + half * 64 + lane;
-                const int8_t* src = planes + p * plane + ((size_t)(s * cfg::chunks + q) * A.npad + rec) * 16;
-                po_glds16(src, dst + ((p * 2 + side) * cfg::chunks + q) * kChunkBytes + half * 1024);
-            }
-        };
-        auto stage_terms = [&](const tile_at& t) {                     // 6 x 128 doubles = six one-KiB LDS-DMA instructions
-#pragma unroll
-            for (int a = 0; a < (METRIC == PO_EUCL ? 3 : 1); ++a)
-#pragma unroll
-                for (int side = 0; side < 2; ++side)
-                    po_glds16(rs + a * A.npad + (side ? t.j0 : t.i0) + 2 * lane, reinterpret_cast<unsigned char*>(terms + a * 256 + side * 128));
-        };
-        uint32_t g = 0;                                                // global step counter: slot = g & 1
-        uint64_t w = blockIdx.x;
-        if (w >= nb) return;                                           // (uniform over the workgroup: blockIdx.x)
-        // The loader runs up to two steps ahead - the depth of the ring - also across tiles: steps 0 and 1 of the next tile are
-        // on their way while the computing waves do the float64 arithmetic of this one (barrier E0 tells the loader that the
-        // last step has been consumed; without it step 1 could only follow E1 and its latency would be exposed in every tile).
-        const uint32_t pre = steps < 2 ? steps : 2;                    // steps of a tile that are issued before its b_0
-        tile_at cur = locate(w);
-        stage(cur, 0, 0);
-        if (pre == 2) stage(cur, 1, 1);
-        stage_terms(cur);
-        for (; w < nb; w += gridDim.x) {
-            const uint64_t wn = w + gridDim.x;
-            const bool more = wn < nb;
-            const tile_at nxt = locate(more ? wn : w);
-            for (uint32_t s = 0; s < steps; ++s, ++g) {
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");    // b_g: step g has landed (and the terms with step 0)
-                if (s + 1 < steps) { if (s + 1 >= pre) stage(cur, s + 1, (g + 1) & 1); }   // the slot of step g - 1 is free: refill it
-                else if (more) stage(nxt, 0, (g + 1) & 1);
-            }
-            asm volatile("s_barrier" ::: "memory");                    // E0: every step of this tile has been consumed
-            if (more && pre == 2) stage(nxt, 1, (g + 1) & 1);          // g counts the next tile's step 0 from here on
-            asm volatile("s_barrier" ::: "memory");                    // E1: the terms buffer is free
-            if (more) stage_terms(nxt);
-            cur = nxt;
-        }
-        return;
-    }
-
-    // ================= the computing waves =================
-    const uint32_t wr = wave >> 1, wc = wave & 1;          // 4 x 2 waves of 32 x 64
+    const uint32_t t = threadIdx.x;
+    const uint32_t lane = t & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
     const uint32_t lr = lane & 31, lh = lane >> 5;
-    constexpr int NG = 2 * P - 1;
-    uint32_t g_step = 0;
-    for (uint64_t w = blockIdx.x; w < nb; w += gridDim.x) {
-        uint32_t ti, tj, pr, pc;
-        list_tile(A, tiles, w, ti, tj);
-        planes_of(ti, tj, pr, pc);
-        const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN;
-        v16i g[NG][2];
+    const uint32_t xcd = blockIdx.x % kXcds, v = blockIdx.x / kXcds;
+    const uint32_t hcol = v & 1;                                       // which half of the tile's columns
+    const uint64_t w = (uint64_t)(v >> 1) * kXcds + xcd;               // the tile's virtual workgroup index (w % 8 = this XCD)
+    if (w >= tiles.count) return;                                      // (uniform: the grid is rounded up to whole groups of 8)
+    uint32_t ti, tj;
+    list_tile(A, tiles, w, ti, tj);
+    const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN + hcol * 64;
+    const size_t plane = (size_t)A.npad * dpad;
+
+    v16i g[3][2];
 #pragma unroll
-        for (int s = 0; s < NG; ++s)
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) g[s][nn][e] = 0;
+
+    for (uint32_t k0 = 0; k0 < dpad; k0 += kHalfKch) {
+        __syncthreads();                                   // the previous step's operand reads are done
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {                      // 24 one-KiB LDS-DMA instructions, 6 per wave: 16 for the rows, 8 for the columns
+            const uint32_t idx = wave * 6 + u;
+            if (idx < 16) {
+                const uint32_t p = idx >> 3, q = (idx >> 1) & 3, half = idx & 1;
+                po_glds16(planes + p * plane + ((size_t)(k0 / 16 + q) * A.npad + i0 + half * 64 + lane) * 16,
+                          smem + (p * 4 + q) * kChunkBytes + half * 1024);
+            } else {
+                const uint32_t p = (idx - 16) >> 2, q = (idx - 16) & 3;
+                po_glds16(planes + p * plane + ((size_t)(k0 / 16 + q) * A.npad + j0 + lane) * 16,
+                          smem + kHalfStageA + (p * 4 + q) * (kChunkBytes / 2));
+            }
+        }
+        __syncthreads();                                   // drains the LDS-DMA (vmcnt) of every wave
+#pragma unroll
+        for (int s = 0; s < kHalfKch / 32; ++s) {
+            const uint32_t q = 2 * s + lh;                 // lane halves take the two 16-byte chunks of a k-step
+            v4i a[2], b[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                a[p] = *reinterpret_cast<const v4i*>(smem + (p * 4 + q) * kChunkBytes + (wave * 32 + lr) * 16);
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn)
+                    b[p][nn] = *reinterpret_cast<const v4i*>(smem + kHalfStageA + (p * 4 + q) * (kChunkBytes / 2) + (nn * 32 + lr) * 16);
+            }
 #pragma unroll
             for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) g[s][nn][e] = 0;
-        for (uint32_t s = 0; s < steps; ++s, ++g_step) {
-            po_lds_barrier();                              // b_g: this step has landed; our reads of the previous one are done
-            const unsigned char* slot = ring + (g_step & 1) * cfg::step_bytes;
+                for (int pa = 0; pa < 2; ++pa)
 #pragma unroll
-            for (int ks = 0; ks < cfg::kch / 32; ++ks) {
-                const uint32_t q = 2 * ks + lh;            // lane halves take the two 16-byte chunks of a k-step
-                v4i a[P], b[P][2];
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    if (P != 3 || (uint32_t)p < pr)
-                        a[p] = *reinterpret_cast<const v4i*>(slot + ((p * 2 + 0) * cfg::chunks + q) * kChunkBytes + (wr * 32 + lr) * 16);
-                    if (P != 3 || (uint32_t)p < pc) {
-#pragma unroll
-                        for (int nn = 0; nn < 2; ++nn)
-                            b[p][nn] = *reinterpret_cast<const v4i*>(slot + ((p * 2 + 1) * cfg::chunks + q) * kChunkBytes + (wc * 64 + nn * 32 + lr) * 16);
-                    }
-                }
-#pragma unroll
-                for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-                    for (int pa = 0; pa < P; ++pa)
-#pragma unroll
-                        for (int pb = 0; pb < P; ++pb)
-                            if (P != 3 || ((uint32_t)pa < pr && (uint32_t)pb < pc))
-                                g[pa + pb][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pa], b[pb][nn], g[pa + pb][nn], 0, 0, 0);
-            }
+                    for (int pb = 0; pb < 2; ++pb)
+                        g[pa + pb][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pa], b[pb][nn], g[pa + pb][nn], 0, 0, 0);
         }
-        po_lds_barrier();                                  // E0: the ring is free (the loader sends the next tile's second step)
-        gram_i8_values_to_tile<P, METRIC, (P == 1 ? 4 : 2)>(g, terms, wr * 32, wr * 32, wc, lr, lh, ti == tj, tl);
-        po_lds_barrier();                                  // E1: the scratch is complete
-        // (the lane index is derived again for every tile: what the store addresses need per lane would otherwise be computed
-        //  once in front of the tile loop, live across it, spilled - and reloading it would wait for the stores in flight)
-        uint32_t lane_s;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
-        po_store_tile_f32<kStreamWaves>(A, po_tile_mirrors(A, ti, tj), i0, j0, wave, lane_s, tl);
     }
+    __syncthreads();                                       // the staging area becomes the scratch
+    // (lane coordinates derived again: anything per-lane that lives across the matrix-core loop is spilled at the register limit)
+    uint32_t lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const uint32_t t_e = wave * 64u + lane_e, lr_e = lane_e & 31, lh_e = lane_e >> 5;
+    float* tl = reinterpret_cast<float*>(smem);
+    double* terms = reinterpret_cast<double*>(smem + kHalfScratchBytes);      // [t0 rows 128 | t0 cols (64 used) | t1 .. | t2 ..]
+    if (t_e < 192) {
+        const uint64_t rec = (t_e < 128) ? i0 + t_e : j0 + (t_e - 128);
+        terms[t_e] = rs[rec];
+        terms[256 + t_e] = METRIC == PO_EUCL ? rs[A.npad + rec] : 0.0;
+        terms[512 + t_e] = METRIC == PO_EUCL ? rs[2 * A.npad + rec] : 0.0;
+    }
+    __syncthreads();
+    gram_i8_values_to_tile<2, METRIC, 1, kHalfStride>(g, terms, wave * 32, wave * 32, 0, lr_e, lh_e, ti == tj, tl, hcol * 64);
+    po_lds_barrier();
+    uint32_t lane_s;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+    po_store_tile_f32<kHalfThreads / 64, 128, 64, kHalfStride>(A, po_tile_mirrors(A, ti, tj), i0, j0, wave, lane_s, tl);
 }
+
+// (A persistent variant - one workgroup per CU, eight computing waves that never wait for a store, a ninth wave staging operands and
+//  terms by LDS-DMA, hand-over by s_barrier only - was built first in round 5 and is not in the tree: with ONE workgroup per CU the phases
+//  of a tile add up exactly (19.1 ms skeleton + 8.7 arithmetic + 9.0 stores = 37.4 ms at 200 000 records), because a store instruction is
+//  asynchronous only as deep as the memory pipeline's queues.  profiles/r05_float32_output.txt section 3; git history: 736e647.)
 
 // `count` tiles: all of the block's (d_list == nullptr) or the listed ones.  The kernel runs iff run_above < *maxabs <= run_upto.
 template <int P, int METRIC>
@@ -750,21 +690,19 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
     }
     // (three planes: five accumulator groups = 160 registers of the 168 a wave of a nine-wave workgroup may have - those tiles, the
     //  few that hold a record of more than ~1 Mb, stay with the tile kernel and its float32 tile epilogue)
-    // (word spaces of more than 512 words - k >= 5 - are bound by the matrix cores, not by the epilogue: there two eight-wave
-    //  workgroups per CU beat the one persistent workgroup, k = 6 Spearman 4.15 against 4.66 ms at 20 000 records)
-    if constexpr (P == 2) if (a.out_f32 && dpad <= 512) {
-        // one persistent workgroup per CU (a multiple of the 8 XCDs, so that a workgroup's tiles stay on its XCD's range)
-        auto k = gram_i8_stream_kernel<P, METRIC>;
-        PO_SHMEM(ctx, k, (size_t)stream_cfg<P>::lds_bytes);
-        uint64_t grid = (uint64_t)(ctx->prop.multiProcessorCount > 8 ? ctx->prop.multiProcessorCount / 8 * 8 : 8);
-        if (grid > po_round_up(count, 8)) grid = po_round_up(count, 8);
-        hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kStreamThreads), (size_t)stream_cfg<P>::lds_bytes, ctx->stream, a, planes, dpad, rs,
-                           maxabs, run_above, run_upto, tl);
-        PO_CHECK_LAUNCH("gram_i8_stream_kernel");
+    // two planes: four waves on half a tile, four workgroups per CU (at every width: k = 5 / 6 Spearman 6.1 / 3.3 ms against 7.0 / 3.7
+    // for the eight-wave kernel on whole tiles)
+    if constexpr (P == 2) if (a.out_f32) {
+        auto k = gram_i8_half_kernel<METRIC>;
+        PO_SHMEM(ctx, k, (size_t)kHalfLdsBytes);
+        const uint64_t grid = 2 * po_round_up(count, kXcds);           // both halves of a tile on the tile's XCD
+        hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kHalfThreads), (size_t)kHalfLdsBytes, ctx->stream, a, planes, dpad, rs, maxabs,
+                           run_above, run_upto, tl);
+        PO_CHECK_LAUNCH("gram_i8_half_kernel");
         return PO_OK;
     }
     if (a.out_f32) {
-        if constexpr (P >= 2) {                            // (one plane - and two planes up to 512 words - returned above)
+        if constexpr (P == 3) {                            // (one and two planes returned above)
             auto k = gram_i8_tile_kernel<P, METRIC, float>;
             PO_SHMEM(ctx, k, shmem);
             hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);

@@ -217,17 +217,18 @@ template <> struct po_f32_vec<4> { typedef po_f4v type; };
 template <> struct po_f32_vec<2> { typedef po_f2v type; };
 template <> struct po_f32_vec<1> { typedef float type; };
 
-// Rows i0 .. i0 + ROWS - 1 of a tile that lies inside its block, as stores of VW floats: a row is 128 / VW lanes, a wave
-// instruction covers 64 VW / 128 rows (VW = 4: two rows, 16-byte stores of 512-byte pieces).  `dst` = the matrix entry of (row 0,
-// column 0) of the piece; the scratch holds the piece row-major (TRANSPOSED = false) or column-major (true: the piece is the
-// transposed tile, its rows are columns of the scratch and ROWS counts its COLUMNS).
-template <int NW, int ROWS, int VW, bool TRANSPOSED>
+// A TR x TC piece of the scratch (row stride STRIDE floats) that lies inside its block, as stores of VW floats: a row of the piece in
+// the matrix is WIDTH / VW lanes, a wave instruction covers 64 VW / WIDTH rows (VW = 4, WIDTH = 128: two rows, 16-byte stores of 512-byte
+// pieces).  `dst` = the matrix entry of (row 0, column 0) of the piece; TRANSPOSED = false: the piece as it lies in the scratch (TR rows
+// of TC entries), true: its transpose (TC rows of TR entries: the rows of the piece are columns of the scratch).
+template <int NW, int TR, int TC, int STRIDE, int VW, bool TRANSPOSED>
 __device__ __forceinline__ void po_store_piece_f32(float* dst, uint64_t ld, uint32_t wave, uint32_t lane, const float* tl) {
     typedef typename po_f32_vec<VW>::type vec;
-    constexpr int WIDTH = TRANSPOSED ? ROWS : 128, NROWS = TRANSPOSED ? 128 : ROWS;     // shape of the piece in the matrix
+    constexpr int WIDTH = TRANSPOSED ? TR : TC, NROWS = TRANSPOSED ? TC : TR;        // shape of the piece in the matrix
     constexpr int LPR = WIDTH / VW;                                  // lanes per row
     if constexpr (LPR <= 64) {
         constexpr int RPI = 64 / LPR, IT = NROWS / RPI / NW;          // rows per instruction, instructions per wave
+        static_assert(IT >= 1 && IT * RPI * NW == NROWS, "the waves share the rows of a piece evenly");
         const uint32_t q = lane / LPR, m = lane % LPR;
         const uint32_t r0 = RPI * (wave & (NW - 1)) + q;
         float* out = dst + (uint64_t)r0 * ld + VW * m;
@@ -238,20 +239,21 @@ __device__ __forceinline__ void po_store_piece_f32(float* dst, uint64_t ld, uint
         for (int it = 0; it < IT; ++it) {
             const uint32_t r = r0 + it * RPI * NW;
             if constexpr (!TRANSPOSED) {
-                const float* src = tl + r * kF32TileStride + VW * m;
+                const float* src = tl + r * STRIDE + VW * m;
                 if constexpr (VW == 4) { const float2 a = *reinterpret_cast<const float2*>(src), b = *reinterpret_cast<const float2*>(src + 2); v[it] = vec{a.x, a.y, b.x, b.y}; }
                 else if constexpr (VW == 2) { const float2 a = *reinterpret_cast<const float2*>(src); v[it] = vec{a.x, a.y}; }
                 else v[it] = src[0];
             } else {
-                const float* src = tl + VW * m * kF32TileStride + r;
-                if constexpr (VW == 4) v[it] = vec{src[0], src[kF32TileStride], src[2 * kF32TileStride], src[3 * kF32TileStride]};
-                else if constexpr (VW == 2) v[it] = vec{src[0], src[kF32TileStride]};
+                const float* src = tl + VW * m * STRIDE + r;
+                if constexpr (VW == 4) v[it] = vec{src[0], src[STRIDE], src[2 * STRIDE], src[3 * STRIDE]};
+                else if constexpr (VW == 2) v[it] = vec{src[0], src[STRIDE]};
                 else v[it] = src[0];
             }
         }
 #pragma unroll
         for (int it = 0; it < IT; ++it) __builtin_nontemporal_store(v[it], reinterpret_cast<vec*>(out + it * step));
     } else {                                                          // 128 single floats per row: two instructions per row
+        static_assert(WIDTH == 128, "single floats: 64 or 128 per row");
         constexpr int IT = NROWS / NW, GRP = IT < 8 ? IT : 8;         // (eight rows of reads, then their stores: 16 registers)
         const uint32_t r0 = wave & (NW - 1);
         float* out = dst + (uint64_t)r0 * ld + lane;
@@ -264,7 +266,7 @@ __device__ __forceinline__ void po_store_piece_f32(float* dst, uint64_t ld, uint
                 const uint32_t r = r0 + (g + it) * NW;
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    v[it][h] = TRANSPOSED ? tl[(lane + 64 * h) * kF32TileStride + r] : tl[r * kF32TileStride + lane + 64 * h];
+                    v[it][h] = TRANSPOSED ? tl[(lane + 64 * h) * STRIDE + r] : tl[r * STRIDE + lane + 64 * h];
             }
 #pragma unroll
             for (int it = 0; it < GRP; ++it) {
@@ -283,34 +285,36 @@ __device__ __forceinline__ int po_f32_store_width(const void* base, uint64_t ld,
     return 1;
 }
 
-// All NW waves of the workgroup call this after the values sit in `tl` and a barrier has made them visible.  ROWS = 128: the whole
-// tile; ROWS = 64: one half of it, rows i0 .. i0 + 63 (a kernel that keeps half the scratch - 33 KiB - and makes two passes: its
-// transposed rows then leave as 256-byte pieces).  Tiles inside their block go out without a per-lane test, as 16-byte stores
-// when the rows of the matrix start on 16-byte boundaries (a leading dimension that is a multiple of 4 entries; of 32 entries
-// = whole 128-byte lines is better still, and is what this library's own buffers have), as 8- or 4-byte stores otherwise.
-template <int NW, int ROWS = 128>
+// All NW waves of the workgroup call this after the values sit in `tl` and a barrier has made them visible.  The scratch holds TR rows
+// (i0 ..) of TC columns (j0 ..) of the tile, row stride STRIDE: the whole 128 x 128 tile, its upper or lower half (TR = 64: a kernel that
+// keeps half the scratch - 33 KiB - and makes two passes; its transposed rows then leave as 256-byte pieces) or its left or right half
+// (TC = 64, stride 66: the rows themselves leave as 256-byte pieces).  Tiles inside their block go out without a per-lane test, as
+// 16-byte stores when the rows of the matrix start on 16-byte boundaries (a leading dimension that is a multiple of 4 entries; of 32
+// entries = whole 128-byte lines is better still, and is what this library's own buffers have), as 8- or 4-byte stores otherwise.
+template <int NW, int TR = 128, int TC = 128, int STRIDE = kF32TileStride>
 __device__ __forceinline__ void po_store_tile_f32(const po_tile_args& A, bool mirrors, uint64_t i0, uint64_t j0, uint32_t wave,
                                                   uint32_t lane, const float* tl) {
-    static_assert(ROWS == 128 || ROWS == 64, "whole tiles or halves");
+    static_assert((TR == 128 || TR == 64) && (TC == 128 || TC == 64) && STRIDE >= TC && STRIDE % 2 == 0, "whole tiles or halves");
     float* out = static_cast<float*>(A.out);
     const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
-    const bool inside = i0 >= A.row_begin && i0 + ROWS <= n_rows && j0 >= A.col_begin && j0 + 128 <= n_cols;   // uniform
+    const bool inside = i0 >= A.row_begin && i0 + TR <= n_rows && j0 >= A.col_begin && j0 + TC <= n_cols;   // uniform
     // ---- the rows themselves ----
     if (inside) {
         float* dst = out + (i0 - A.row_begin) * A.ld_out + (j0 - A.col_begin);
         const int vw = po_f32_store_width(A.out, A.ld_out, j0 - A.col_begin);
-        if (vw == 4) po_store_piece_f32<NW, ROWS, 4, false>(dst, A.ld_out, wave, lane, tl);
-        else if (vw == 2) po_store_piece_f32<NW, ROWS, 2, false>(dst, A.ld_out, wave, lane, tl);
-        else po_store_piece_f32<NW, ROWS, 1, false>(dst, A.ld_out, wave, lane, tl);
+        if (vw == 4) po_store_piece_f32<NW, TR, TC, STRIDE, 4, false>(dst, A.ld_out, wave, lane, tl);
+        else if (vw == 2) po_store_piece_f32<NW, TR, TC, STRIDE, 2, false>(dst, A.ld_out, wave, lane, tl);
+        else if constexpr (TC == 128) po_store_piece_f32<NW, TR, TC, STRIDE, 1, false>(dst, A.ld_out, wave, lane, tl);
+        else po_store_piece_f32<NW, TR, TC, STRIDE, 1, false>(dst, A.ld_out, wave, lane, tl);
     } else {
-        for (uint32_t r = wave; r < ROWS; r += NW) {
+        for (uint32_t r = wave; r < TR; r += NW) {
             const uint64_t i = i0 + r;
             if (i < A.row_begin || i >= n_rows) continue;
             float* row = out + (i - A.row_begin) * A.ld_out;
 #pragma unroll
-            for (uint32_t c = lane; c < 128; c += 64) {
+            for (uint32_t c = lane; c < TC; c += 64) {
                 const uint64_t j = j0 + c;
-                if (j >= A.col_begin && j < n_cols) po_out_store(&row[j - A.col_begin], tl[r * kF32TileStride + c]);
+                if (j >= A.col_begin && j < n_cols) po_out_store(&row[j - A.col_begin], tl[r * STRIDE + c]);
             }
         }
     }
@@ -320,18 +324,18 @@ __device__ __forceinline__ void po_store_tile_f32(const po_tile_args& A, bool mi
     if (inside) {
         float* dst = mir + (j0 - A.col_begin) * A.ld_mirror + (i0 - A.row_begin);
         const int vw = po_f32_store_width(A.mirror, A.ld_mirror, i0 - A.row_begin);
-        if (vw == 4) po_store_piece_f32<NW, ROWS, 4, true>(dst, A.ld_mirror, wave, lane, tl);
-        else if (vw == 2) po_store_piece_f32<NW, ROWS, 2, true>(dst, A.ld_mirror, wave, lane, tl);
-        else po_store_piece_f32<NW, ROWS, 1, true>(dst, A.ld_mirror, wave, lane, tl);
+        if (vw == 4) po_store_piece_f32<NW, TR, TC, STRIDE, 4, true>(dst, A.ld_mirror, wave, lane, tl);
+        else if (vw == 2) po_store_piece_f32<NW, TR, TC, STRIDE, 2, true>(dst, A.ld_mirror, wave, lane, tl);
+        else po_store_piece_f32<NW, TR, TC, STRIDE, 1, true>(dst, A.ld_mirror, wave, lane, tl);
     } else {
-        for (uint32_t c = wave; c < 128; c += NW) {
+        for (uint32_t c = wave; c < TC; c += NW) {
             const uint64_t j = j0 + c;
             if (j < A.col_begin || j >= n_cols) continue;
             float* row = mir + (j - A.col_begin) * A.ld_mirror;
 #pragma unroll
-            for (uint32_t r = lane; r < ROWS; r += 64) {
+            for (uint32_t r = lane; r < TR; r += 64) {
                 const uint64_t i = i0 + r;
-                if (i >= A.row_begin && i < n_rows) po_out_store(&row[i - A.row_begin], tl[r * kF32TileStride + c]);
+                if (i >= A.row_begin && i < n_rows) po_out_store(&row[i - A.row_begin], tl[r * STRIDE + c]);
             }
         }
     }
@@ -419,7 +423,7 @@ __device__ __forceinline__ void po_store_block_f32(const po_tile_args& A, uint32
                     *reinterpret_cast<float2*>(row + ia * kF32TileStride + 32 * q) = make_float2((float)v[ia][2 * q], (float)v[ia][2 * q + 1]);
         }
         po_lds_barrier();
-        po_store_tile_f32<NT / 64, 64>(A, mirrors, i0 + 64 * h, j0, wave, lane, tl);
+        po_store_tile_f32<NT / 64, 64, 128>(A, mirrors, i0 + 64 * h, j0, wave, lane, tl);
     }
 }
 
