@@ -35,8 +35,8 @@ KEYS = {"jsd_lut_rows_kernel<double, 16>": ("JSD_n50000_d256", 256), "gram_i8_ti
         "valu_tile_kernel<3, double, 8>": ("BC_ragged_n50000_d256", 256), "gram_i8_tile_kernel<2, 0, double>": ("Eucl_ragged_n50000_d256", 256),
         "bc_sad_tile_kernel<double>": ("BC_sad_n50000", 4096), "gram_i8_tile_kernel<2, 4, double>": ("SC_n50000_d256", 256),
         # float32 matrices (round 5): 8 bytes of output per pair
-        "gram_i8_quad_kernel<0>": ("Eucl_f32_n50000_d256", 256, 8.0), "gram_i8_stream_kernel<2, 0>": ("Eucl_f32_ragged_n50000_d256", 256, 8.0),
-        "gram_i8_stream_kernel<2, 4>": ("SC_f32_n50000_d256", 256, 8.0), "bc_sad_tile_kernel<float>": ("BC_sad_f32_n50000_d256", 256, 8.0)}
+        "gram_i8_quad_kernel<0>": ("Eucl_f32_n50000_d256", 256, 8.0), "gram_i8_half_kernel<0>": ("Eucl_f32_ragged_n50000_d256", 256, 8.0),
+        "gram_i8_half_kernel<4>": ("SC_f32_n50000_d256", 256, 8.0), "bc_sad_tile_kernel<float>": ("BC_sad_f32_n50000_d256", 256, 8.0)}
 _ver, _hash = lib_identity()
 out = {"_detail": {"how": __doc__.split("usage:")[0].strip(), "source": sys.argv[2], "lib_version": _ver, "src_hash": _hash}}
 print("%-46s %14s %16s %14s %14s %8s" % ("kernel (largest dispatch)", "FETCH_SIZE KiB", "fetch B (x2)", "WRITE_SIZE KiB", "traffic B", "/ algo"))

@@ -27,7 +27,7 @@ c, t = profiles("1111", 50001)
 for metric in ("JSD", "Eucl", "BC", "SC", "KT"):
     ctx.pairwise(c, t, metric, out=out)
 ctx.pairwise(c, t, "Eucl", out=out, table_path=False)          # float64 MFMA Gram
-for metric in ("Eucl", "SC", "BC"):                             # float32: gram_i8_quad_kernel, gram_i8_stream_kernel<2, SC>, bc_sad_tile_kernel<float>
+for metric in ("Eucl", "SC", "BC"):                             # float32: gram_i8_quad_kernel, gram_i8_half_kernel<SC>, bc_sad_tile_kernel<float>
     ctx.pairwise(c, t, metric, out=out32, dtype="float32")
 # the ragged, dirty assembly of bench.py's config.ragged_assembly and tests/test_gpu_full_size.py (every tile a mixed tile)
 rseq, roff = synthetic.ragged_assembly(n, seed=2024)
@@ -36,7 +36,7 @@ del rseq
 ctx.pairwise(c, t, "JSD", out=out)                                # general JSD kernel
 ctx.pairwise(c, t, "BC", out=out)                                 # general BC kernel
 ctx.pairwise(c, t, "Eucl", out=out)                               # two digit planes
-ctx.pairwise(c, t, "Eucl", out=out32, dtype="float32")            # two digit planes, float32: gram_i8_stream_kernel<2, Eucl>
+ctx.pairwise(c, t, "Eucl", out=out32, dtype="float32")            # two digit planes, float32: gram_i8_half_kernel<Eucl>
 c, t = profiles("11011011", 50005)
 ctx.pairwise(c, t, "BC", out=out)                                 # C5: thermometer planes on the matrix cores
 ctx.pairwise(c, t, "BC", out=out, pairdot=False)                  # C5 through the packed-byte SAD kernel
