@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s a
 F64_MFMA_PEAK_TF = 78.6   # v_mfma_f64_16x16x4_f64 dense peak
 
 KERNEL_NAMES = {1: "valu_tile_kernel<JSD>", 2: "valu_tile_kernel<BC>", 3: "gram_tile_kernel (f64 MFMA)",
-                4: "gram_i8_tile_kernel (exact int8 MFMA)", 5: "kt_tile_kernel",
+                4: "gram_i8_quad|half|tile_kernel (exact int8 MFMA)", 5: "kt_tile_kernel",
                 6: "jsd_lut_rows_kernel (equal-total record blocks) + valu_tile_kernel<JSD> (rest)",
                 7: "bc_sad_tile_kernel (equal-total record blocks) + valu_tile_kernel<BC> (rest)",
                 8: "pairdot_tile_kernel<KT> (materialised pair-sign Gram on the matrix cores)",
@@ -473,7 +473,7 @@ def main():
         if busy.get("_src_hash") != lib_hash:
             stale.append("profiles/pmc_busy.json (every roofline.binding): measured on src %s" % busy.get("_src_hash"))
 
-        main_key = {6: "jsd_lut_rows_kernel", 1: "valu_tile_kernel<JSD>", 4: "gram_i8_tile_kernel<1>", 3: "gram_tile_kernel<f64>",
+        main_key = {6: "jsd_lut_rows_kernel", 1: "valu_tile_kernel<JSD>", 4: "gram_i8_quad_kernel<f64>", 3: "gram_tile_kernel<f64>",
                     7: "bc_sad_tile_kernel", 2: "valu_tile_kernel<BC>", 8: "pairdot_tile_kernel<KT>", 9: "pairdot_tile_kernel<BC>"}.get(main_kernel_id)
         roof = hbm_roofline(bytes_per_pair * rank_pairs, kernel_ms, traffic=traffic if world == 1 else None, traffic_source=traffic_source,
                             kernel=KERNEL_NAMES.get(main_kernel_id, "tile kernel"), kernel_ms=kernel_ms, bytes_per_pair=bytes_per_pair,
@@ -549,7 +549,7 @@ def main():
                 e = timed(counts, totals, "Eucl")
                 e["roofline"]["traffic"] = traffic_all.get("Eucl_n%d_d%d" % (n, dim))
                 e["roofline"]["bound"] = "hbm-store"
-                e["roofline"]["binding"] = binding("gram_i8_tile_kernel<1>")
+                e["roofline"]["binding"] = binding("gram_i8_quad_kernel<f64>")
                 e["roofline"]["note"] = ("exact int8-MFMA Gram: matrix-core time ~0.1 ms, the kernel is bound by writing 16 B per pair; "
                                          "bare store pattern of this tiling measures 6.1 TB/s (profiles/r01_store_bandwidth.txt)")
                 others["C3 Eucl k=4 (default path: exact int8 MFMA)"] = e

@@ -24,6 +24,7 @@
 // Eligibility is decided on the device from the largest |value| of the matrix: every candidate kernel is
 // launched and all but one exit at once (no host synchronisation); see po_api.hip.
 #include "po_tiles.h"
+#include <type_traits>
 
 namespace {
 
@@ -205,9 +206,9 @@ __device__ __forceinline__ double gram_i8_value(const double G, const double t0r
 // instructions in a basic block of their own; written like this, N independent chains are in flight in one wave, which is what
 // two waves per SIMD need to keep the vector ALU busy (the persistent variant of round 5, and any kernel at low occupancy).  Where its bit is clear a result equals
 // gram_i8_value's bit for bit.
-template <int METRIC, int N>
+template <int METRIC, int N, typename OUT>
 __device__ __forceinline__ uint32_t gram_i8_values_fast(const double (&G)[N], const double (&t0r)[N], const double (&t1r)[N],
-                                                        const double (&t0c)[N], const double (&t1c)[N], float (&out)[N]) {
+                                                        const double (&t0c)[N], const double (&t1c)[N], OUT (&out)[N]) {
     uint32_t special = 0;
     double x[N], y[N];
     if (METRIC == PO_EUCL) {
@@ -229,7 +230,7 @@ __device__ __forceinline__ uint32_t gram_i8_values_fast(const double (&G)[N], co
 #pragma unroll
         for (int e = 0; e < N; ++e) r[e] = fma(-gg[e], gg[e], x[e]);
 #pragma unroll
-        for (int e = 0; e < N; ++e) out[e] = (float)fma(r[e], h[e], gg[e]);
+        for (int e = 0; e < N; ++e) out[e] = (OUT)fma(r[e], h[e], gg[e]);
     } else {
 #pragma unroll
         for (int e = 0; e < N; ++e) { x[e] = t0r[e] * t0c[e]; special |= (G[e] == t0r[e] && G[e] == t0c[e]) ? (1u << e) : 0u; }
@@ -240,7 +241,7 @@ __device__ __forceinline__ uint32_t gram_i8_values_fast(const double (&G)[N], co
 #pragma unroll
             for (int e = 0; e < N; ++e) y[e] = fma(0.5 * y[e], fma(-(x[e] * y[e]), y[e], 1.0), y[e]);
 #pragma unroll
-        for (int e = 0; e < N; ++e) out[e] = (float)(1.0 - G[e] * y[e]);
+        for (int e = 0; e < N; ++e) out[e] = (OUT)(1.0 - G[e] * y[e]);
     }
     asm volatile("" : "+v"(special));                      // the comparisons are made here, not collected at the end of the caller
     return special;
@@ -250,19 +251,24 @@ __device__ __forceinline__ uint32_t gram_i8_values_fast(const double (&G)[N], co
 // 64 wc .. - from its accumulators into the float32 tile scratch `tl` (po_tiles.h).  Accumulator layout (32x32): column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  kIlpRows rows
 // = 2 kIlpRows pairs are in flight at a time (every pair holds ~10 registers); the rare cases follow wave by wave.
 // terms: [t0 rows | t0 cols | t1 rows | t1 cols | t2 rows | t2 cols] of the tile's 128 + 128 records (LDS).
-template <int P, int METRIC, int kIlpRows, int STRIDE = kF32TileStride>
+// REG0, NREG: the accumulator registers taken (all sixteen = the block's 32 rows; eight = sixteen of them, for the kernels that fill a
+// scratch of fewer rows in several passes): register reg stands for row (reg & 3) + 8 ((reg - REG0) >> 2) + 4 (lane >> 5) behind rrow / trow.
+template <int P, int METRIC, int kIlpRows, int STRIDE = kF32TileStride, typename OUT = float, int REG0 = 0, int NREG = 16>
 __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1][2], const double* terms, const uint32_t rrow,
                                                        const uint32_t trow, const uint32_t wc, const uint32_t lr, const uint32_t lh,
-                                                       const bool diag_tile, float* tl, const uint32_t ccol_of_block = 0xFFFFFFFFu) {
+                                                       const bool diag_tile, OUT* tl, const uint32_t ccol_of_block = 0xFFFFFFFFu) {
     constexpr int NG = 2 * P - 1;
     // the block's first column inside the tile (for the diagonal of the matrix): 64 wc, unless the scratch is a column half of the tile
     const uint32_t ccol = ccol_of_block == 0xFFFFFFFFu ? wc * 64 : ccol_of_block;
     const double* t0r = terms + rrow, *t0c = terms + 128 + wc * 64;             // Eucl: S/n^2      SC: N
     const double* t1r = terms + 256 + rrow, *t1c = terms + 384 + wc * 64;       // Eucl: 1/n
     const double* t2r = terms + 512 + rrow, *t2c = terms + 640 + wc * 64;       // Eucl: S
-    float* wt = tl + (trow + 4 * lh) * STRIDE + wc * 64 + lr;
-    const double tc0 = t0c[lr], tc1 = t0c[32 + lr];
-    const double ic0 = METRIC == PO_EUCL ? t1c[lr] : 0.0, ic1 = METRIC == PO_EUCL ? t1c[32 + lr] : 0.0;
+    OUT* wt = tl + (trow + 4 * lh) * STRIDE + wc * 64 + lr;
+    // (two planes into a float64 scratch: 96 accumulators and value pairs of two registers each leave no room for the eight registers of
+    //  column terms - they are read from the LDS again for every row, behind a lane index the compiler cannot see through)
+    constexpr bool kReloadCols = sizeof(OUT) == 8 && P >= 2;
+    double tc0 = t0c[lr], tc1 = t0c[32 + lr];
+    double ic0 = METRIC == PO_EUCL ? t1c[lr] : 0.0, ic1 = METRIC == PO_EUCL ? t1c[32 + lr] : 0.0;
     auto gram = [&](const int nn, const int reg) -> double {
         double G = (double)g[NG - 1][nn][reg];         // Horner in 128: every partial sum an exact integer below 2^53
 #pragma unroll
@@ -271,25 +277,31 @@ __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1
     };
     uint32_t special = 0;
 #pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += kIlpRows) {
+    for (int r0 = REG0; r0 < REG0 + NREG; r0 += kIlpRows) {
         double G[2 * kIlpRows], a0[2 * kIlpRows], a1[2 * kIlpRows], b0[2 * kIlpRows], b1[2 * kIlpRows];
-        float v[2 * kIlpRows];
+        OUT v[2 * kIlpRows];
+        if constexpr (kReloadCols) {
+            uint32_t lrx = lr;
+            asm volatile("" : "+v"(lrx));
+            tc0 = t0c[lrx]; tc1 = t0c[32 + lrx];
+            if (METRIC == PO_EUCL) { ic0 = t1c[lrx]; ic1 = t1c[32 + lrx]; }
+        }
 #pragma unroll
         for (int e = 0; e < kIlpRows; ++e) {
             const int reg = r0 + e;
-            const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            const uint32_t rl = (reg & 3) + 8 * ((reg - REG0) >> 2) + 4 * lh;
             G[2 * e] = gram(0, reg); G[2 * e + 1] = gram(1, reg);
             a0[2 * e] = a0[2 * e + 1] = t0r[rl];
             a1[2 * e] = a1[2 * e + 1] = METRIC == PO_EUCL ? t1r[rl] : 0.0;
             b0[2 * e] = tc0; b0[2 * e + 1] = tc1;
             b1[2 * e] = ic0; b1[2 * e + 1] = ic1;
         }
-        special |= gram_i8_values_fast<METRIC, 2 * kIlpRows>(G, a0, a1, b0, b1, v);
+        special |= gram_i8_values_fast<METRIC, 2 * kIlpRows, OUT>(G, a0, a1, b0, b1, v);
         asm volatile("" : "+v"(special));                  // one running word, not sixteen partial ones kept for a tree of ORs
 #pragma unroll
         for (int e = 0; e < kIlpRows; ++e) {
             const int reg = r0 + e;
-            float* wp = wt + ((reg & 3) + 8 * (reg >> 2)) * STRIDE;
+            OUT* wp = wt + ((reg & 3) + 8 * ((reg - REG0) >> 2)) * STRIDE;
             wp[0] = v[2 * e];
             wp[32] = v[2 * e + 1];
         }
@@ -311,12 +323,12 @@ __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1
             return G;
         };
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const uint32_t rl = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        for (int reg = REG0; reg < REG0 + NREG; ++reg) {
+            const uint32_t rl = (reg & 3) + 8 * ((reg - REG0) >> 2) + 4 * lh;
             const double trr = t0r[rl], irr = METRIC == PO_EUCL ? t1r[rl] : 0.0;
-            float* wp = wt + ((reg & 3) + 8 * (reg >> 2)) * STRIDE;
-            wp[0] = (float)gram_i8_value<METRIC>(gram_again(0, reg), trr, irr, t2r + rl, tc0, ic0, t2c + lr, diag_tile && rrow + rl == ccol + lr);
-            wp[32] = (float)gram_i8_value<METRIC>(gram_again(1, reg), trr, irr, t2r + rl, tc1, ic1, t2c + 32 + lr, diag_tile && rrow + rl == ccol + 32 + lr);
+            OUT* wp = wt + ((reg & 3) + 8 * ((reg - REG0) >> 2)) * STRIDE;
+            wp[0] = (OUT)gram_i8_value<METRIC>(gram_again(0, reg), trr, irr, t2r + rl, tc0, ic0, t2c + lr, diag_tile && rrow + rl == ccol + lr);
+            wp[32] = (OUT)gram_i8_value<METRIC>(gram_again(1, reg), trr, irr, t2r + rl, tc1, ic1, t2c + 32 + lr, diag_tile && rrow + rl == ccol + 32 + lr);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -485,7 +497,7 @@ constexpr int kQuadThreads = 256;
 constexpr int kQuadScratchBytes = 64 * kF32TileStride * 4;             // 33 280 B (the 32 KiB staging area lies underneath)
 constexpr int kQuadLdsBytes = kQuadScratchBytes + kTermBytes;
 
-template <int METRIC>
+template <int METRIC, typename OUT>
 __global__ __launch_bounds__(kQuadThreads, 4) void gram_i8_quad_kernel(po_tile_args A, const int8_t* __restrict__ planes, uint32_t dpad,
                                                                        const double* __restrict__ rs, const uint32_t* __restrict__ maxabs,
                                                                        long long run_above, long long run_upto, tile_list tiles) {
@@ -512,6 +524,13 @@ __global__ __launch_bounds__(kQuadThreads, 4) void gram_i8_quad_kernel(po_tile_a
             po_glds16(rs + a * A.npad + (side ? j0 : i0) + 2 * lane, reinterpret_cast<unsigned char*>(terms + a * 256 + side * 128));
     }
 
+    // Which tile row a lane's operand row stands for.  float32: row block bi of wave row wr = tile rows 64 bi + 32 wr + m (the scratch holds
+    // 64 rows: two passes, "block bi of every wave").  float64: the same 33 KiB hold 32 rows of doubles, so the epilogue makes FOUR passes
+    // and a pass must be 32 consecutive tile rows with every wave contributing: m = 16 hi + m' of wave row wr = tile row 64 bi + 32 hi +
+    // 16 wr + m' - registers 8 hi .. 8 hi + 7 of block bi are pass 2 bi + hi.
+    constexpr bool F64 = sizeof(OUT) == 8;
+    const uint32_t arow = F64 ? 32 * (lr >> 4) + 16 * wr + (lr & 15) : wr * 32 + lr;
+
     v16i g[2][1][2];                                       // [row block bi][plane sum][column block]
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi)
@@ -535,7 +554,7 @@ __global__ __launch_bounds__(kQuadThreads, 4) void gram_i8_quad_kernel(po_tile_a
             const uint32_t q = 2 * s + lh;                 // lane halves take the two 16-byte chunks of a k-step
             v4i a[2], b[2];
 #pragma unroll
-            for (int bi = 0; bi < 2; ++bi) a[bi] = *reinterpret_cast<const v4i*>(smem + q * kChunkBytes + (bi * 64 + wr * 32 + lr) * 16);
+            for (int bi = 0; bi < 2; ++bi) a[bi] = *reinterpret_cast<const v4i*>(smem + q * kChunkBytes + (bi * 64 + arow) * 16);
 #pragma unroll
             for (int nn = 0; nn < 2; ++nn) b[nn] = *reinterpret_cast<const v4i*>(smem + (8 + q) * kChunkBytes + (wc * 64 + nn * 32 + lr) * 16);
 #pragma unroll
@@ -549,18 +568,29 @@ __global__ __launch_bounds__(kQuadThreads, 4) void gram_i8_quad_kernel(po_tile_a
     uint32_t lane_e;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     const uint32_t lr_e = lane_e & 31, lh_e = lane_e >> 5;
-    float* tl = reinterpret_cast<float*>(smem);
+    OUT* tl = reinterpret_cast<OUT*>(smem);
     const bool mirror = po_tile_mirrors(A, ti, tj);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        po_lds_barrier();                                  // terms in place (h = 0); the stores of the upper half have read the scratch (h = 1)
-        gram_i8_values_to_tile<1, METRIC, 2>(g[h], terms, h * 64 + wr * 32, wr * 32, wc, lr_e, lh_e, ti == tj, tl);
+    constexpr int kPasses = F64 ? 4 : 2, kPassRows = 128 / kPasses;
+    auto pass = [&](auto H) {                              // (the pass number is a template argument of the value function)
+        constexpr int h = decltype(H)::value;
+        po_lds_barrier();                                  // terms in place (h = 0); the stores of the pass before have read the scratch
+        if constexpr (F64)
+            gram_i8_values_to_tile<1, METRIC, 2, kF32TileStride, double, 8 * (h & 1), 8>(g[h >> 1], terms, h * 32 + wr * 16, wr * 16, wc, lr_e, lh_e,
+                                                                                     ti == tj, tl);
+        else
+            gram_i8_values_to_tile<1, METRIC, 2>(g[h], terms, h * 64 + wr * 32, wr * 32, wc, lr_e, lh_e, ti == tj, tl);
         po_lds_barrier();
-        // (the lane index once more, per pass: store addresses shared between the passes would stay live across the second pass's
-        //  arithmetic - next to its 32 accumulators - and spill)
+        // (the lane index once more, per pass: store addresses shared between the passes would stay live across the next pass's
+        //  arithmetic - next to its accumulators - and spill)
         uint32_t lane_s;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
-        po_store_tile_f32<kQuadThreads / 64, 64>(A, mirror, i0 + h * 64, j0, wave, lane_s, tl);
+        po_store_tile<OUT, kQuadThreads / 64, kPassRows, 128, kF32TileStride>(A, mirror, i0 + h * kPassRows, j0, wave, lane_s, tl);
+    };
+    pass(std::integral_constant<int, 0>{});
+    pass(std::integral_constant<int, 1>{});
+    if constexpr (F64) {
+        pass(std::integral_constant<int, 2>{});
+        pass(std::integral_constant<int, 3>{});
     }
 }
 
@@ -579,7 +609,7 @@ constexpr int kHalfStageBytes = kHalfStageA + kHalfStageA / 2;         // + the 
 constexpr int kHalfScratchBytes = 128 * kHalfStride * 4;               // 33 792 B, over the staging area
 constexpr int kHalfLdsBytes = kHalfScratchBytes + kTermBytes;
 
-template <int METRIC>
+template <int METRIC, typename OUT>
 __global__ __launch_bounds__(kHalfThreads, 4) void gram_i8_half_kernel(po_tile_args A, const int8_t* __restrict__ planes, uint32_t dpad,
                                                                        const double* __restrict__ rs, const uint32_t* __restrict__ maxabs,
                                                                        long long run_above, long long run_upto, tile_list tiles) {
@@ -601,6 +631,10 @@ __global__ __launch_bounds__(kHalfThreads, 4) void gram_i8_half_kernel(po_tile_a
     const uint64_t i0 = (uint64_t)ti * TM, j0 = (uint64_t)tj * TN + hcol * 64;
     const size_t plane = (size_t)A.npad * dpad;
 
+    // float32: wave w holds tile rows 32 w + m, the scratch the whole half (128 x 64).  float64: the same 33 KiB hold 64 rows of doubles -
+    // two passes, each 64 consecutive tile rows with every wave contributing: m = 16 hi + m' of wave w = tile row 64 hi + 16 w + m'.
+    constexpr bool F64 = sizeof(OUT) == 8;
+    const uint32_t arow = F64 ? 64 * (lr >> 4) + 16 * wave + (lr & 15) : wave * 32 + lr;
     v16i g[3][2];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -631,7 +665,7 @@ __global__ __launch_bounds__(kHalfThreads, 4) void gram_i8_half_kernel(po_tile_a
             v4i a[2], b[2][2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                a[p] = *reinterpret_cast<const v4i*>(smem + (p * 4 + q) * kChunkBytes + (wave * 32 + lr) * 16);
+                a[p] = *reinterpret_cast<const v4i*>(smem + (p * 4 + q) * kChunkBytes + arow * 16);
 #pragma unroll
                 for (int nn = 0; nn < 2; ++nn)
                     b[p][nn] = *reinterpret_cast<const v4i*>(smem + kHalfStageA + (p * 4 + q) * (kChunkBytes / 2) + (nn * 32 + lr) * 16);
@@ -650,7 +684,7 @@ __global__ __launch_bounds__(kHalfThreads, 4) void gram_i8_half_kernel(po_tile_a
     uint32_t lane_e;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     const uint32_t t_e = wave * 64u + lane_e, lr_e = lane_e & 31, lh_e = lane_e >> 5;
-    float* tl = reinterpret_cast<float*>(smem);
+    OUT* tl = reinterpret_cast<OUT*>(smem);
     double* terms = reinterpret_cast<double*>(smem + kHalfScratchBytes);      // [t0 rows 128 | t0 cols (64 used) | t1 .. | t2 ..]
     if (t_e < 192) {
         const uint64_t rec = (t_e < 128) ? i0 + t_e : j0 + (t_e - 128);
@@ -659,11 +693,30 @@ __global__ __launch_bounds__(kHalfThreads, 4) void gram_i8_half_kernel(po_tile_a
         terms[512 + t_e] = METRIC == PO_EUCL ? rs[2 * A.npad + rec] : 0.0;
     }
     __syncthreads();
-    gram_i8_values_to_tile<2, METRIC, 1, kHalfStride>(g, terms, wave * 32, wave * 32, 0, lr_e, lh_e, ti == tj, tl, hcol * 64);
-    po_lds_barrier();
-    uint32_t lane_s;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
-    po_store_tile_f32<kHalfThreads / 64, 128, 64, kHalfStride>(A, po_tile_mirrors(A, ti, tj), i0, j0, wave, lane_s, tl);
+    const bool mirror = po_tile_mirrors(A, ti, tj);
+    if constexpr (!F64) {
+        gram_i8_values_to_tile<2, METRIC, 1, kHalfStride>(g, terms, wave * 32, wave * 32, 0, lr_e, lh_e, ti == tj, tl, hcol * 64);
+        po_lds_barrier();
+        uint32_t lane_s;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+        po_store_tile<float, kHalfThreads / 64, 128, 64, kHalfStride>(A, mirror, i0, j0, wave, lane_s, tl);
+    } else {
+        auto pass = [&](auto H) {
+            constexpr int h = decltype(H)::value;
+            if (h) po_lds_barrier();                       // the stores of the upper rows have read the scratch
+            // (lane coordinates per pass: LDS addresses shared between the passes would live across the first one's arithmetic and spill)
+            uint32_t lane_p;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_p));
+            gram_i8_values_to_tile<2, METRIC, 1, kHalfStride, double, 8 * h, 8>(g, terms, h * 64 + wave * 16, wave * 16, 0, lane_p & 31, lane_p >> 5,
+                                                                                ti == tj, tl, hcol * 64);
+            po_lds_barrier();
+            uint32_t lane_s;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+            po_store_tile<double, kHalfThreads / 64, 64, 64, kHalfStride>(A, mirror, i0 + h * 64, j0, wave, lane_s, tl);
+        };
+        pass(std::integral_constant<int, 0>{});
+        pass(std::integral_constant<int, 1>{});
+    }
 }
 
 // (A persistent variant - one workgroup per CU, eight computing waves that never wait for a store, a ninth wave staging operands and
@@ -681,36 +734,49 @@ int launch_tiles(po_ctx* ctx, const po_tile_args& a, const int8_t* planes, uint3
     const size_t staging = (size_t)P * 2 * 8 * kChunkBytes;
     const size_t scratch = a.out_f32 ? (size_t)kF32TileBytes : (size_t)kMirrorBytes;      // the epilogue's LDS, over the staging area
     const size_t shmem = (staging > scratch ? staging : scratch) + kTermBytes;
-    if constexpr (P == 1) if (a.out_f32) {
-        auto k = gram_i8_quad_kernel<METRIC>;
-        PO_SHMEM(ctx, k, (size_t)kQuadLdsBytes);
-        hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kQuadThreads), (size_t)kQuadLdsBytes, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
+    // one plane: four waves of 64 x 64 pairs; two planes: four waves on half a tile (at every width: k = 5 / 6 Spearman in float32 6.1 /
+    // 3.3 ms against 7.0 / 3.7 for the eight-wave kernel on whole tiles) - four workgroups per CU, either output type
+    if constexpr (P == 1) {
+        if (a.out_f32) {
+            auto k = gram_i8_quad_kernel<METRIC, float>;
+            PO_SHMEM(ctx, k, (size_t)kQuadLdsBytes);
+            hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kQuadThreads), (size_t)kQuadLdsBytes, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
+        } else {
+            auto k = gram_i8_quad_kernel<METRIC, double>;
+            PO_SHMEM(ctx, k, (size_t)kQuadLdsBytes);
+            hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kQuadThreads), (size_t)kQuadLdsBytes, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
+        }
         PO_CHECK_LAUNCH("gram_i8_quad_kernel");
         return PO_OK;
     }
-    // (three planes: five accumulator groups = 160 registers of the 168 a wave of a nine-wave workgroup may have - those tiles, the
-    //  few that hold a record of more than ~1 Mb, stay with the tile kernel and its float32 tile epilogue)
-    // two planes: four waves on half a tile, four workgroups per CU (at every width: k = 5 / 6 Spearman 6.1 / 3.3 ms against 7.0 / 3.7
-    // for the eight-wave kernel on whole tiles)
-    if constexpr (P == 2) if (a.out_f32) {
-        auto k = gram_i8_half_kernel<METRIC>;
-        PO_SHMEM(ctx, k, (size_t)kHalfLdsBytes);
+    // (float64 from 2 048 words on - k = 6 Spearman, matrix-core bound - is the one case left to the eight-wave kernel: 3.26 against 3.46 ms
+    //  at 20 000 records; k = 5: half tiles 6.75 against 6.9)
+    if constexpr (P == 2) if (a.out_f32 || dpad < 2048) {
         const uint64_t grid = 2 * po_round_up(count, kXcds);           // both halves of a tile on the tile's XCD
-        hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kHalfThreads), (size_t)kHalfLdsBytes, ctx->stream, a, planes, dpad, rs, maxabs,
-                           run_above, run_upto, tl);
+        if (a.out_f32) {
+            auto k = gram_i8_half_kernel<METRIC, float>;
+            PO_SHMEM(ctx, k, (size_t)kHalfLdsBytes);
+            hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kHalfThreads), (size_t)kHalfLdsBytes, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
+        } else {
+            auto k = gram_i8_half_kernel<METRIC, double>;
+            PO_SHMEM(ctx, k, (size_t)kHalfLdsBytes);
+            hipLaunchKernelGGL(k, dim3((uint32_t)grid), dim3(kHalfThreads), (size_t)kHalfLdsBytes, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
+        }
         PO_CHECK_LAUNCH("gram_i8_half_kernel");
         return PO_OK;
     }
-    if (a.out_f32) {
-        if constexpr (P == 3) {                            // (one and two planes returned above)
-            auto k = gram_i8_tile_kernel<P, METRIC, float>;
+    if constexpr (P >= 2) {                                // three planes: eight waves on whole tiles (160 accumulator registers)
+        if (a.out_f32) {
+            if constexpr (P == 3) {
+                auto k = gram_i8_tile_kernel<P, METRIC, float>;
+                PO_SHMEM(ctx, k, shmem);
+                hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
+            }
+        } else {
+            auto k = gram_i8_tile_kernel<P, METRIC, double>;
             PO_SHMEM(ctx, k, shmem);
             hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
         }
-    } else {
-        auto k = gram_i8_tile_kernel<P, METRIC, double>;
-        PO_SHMEM(ctx, k, shmem);
-        hipLaunchKernelGGL(k, dim3((uint32_t)count), dim3(kThreads), shmem, ctx->stream, a, planes, dpad, rs, maxabs, run_above, run_upto, tl);
     }
     PO_CHECK_LAUNCH("gram_i8_tile_kernel");
     return PO_OK;

@@ -211,19 +211,21 @@ constexpr int kF32TileBytes = 128 * kF32TileStride * 4;              // 66 560 B
 
 typedef float po_f4v __attribute__((ext_vector_type(4)));
 
-// VW consecutive floats of the scratch as one store: 16, 8 or 4 bytes
-template <int VW> struct po_f32_vec;
-template <> struct po_f32_vec<4> { typedef po_f4v type; };
-template <> struct po_f32_vec<2> { typedef po_f2v type; };
-template <> struct po_f32_vec<1> { typedef float type; };
+// VW consecutive entries of the scratch as one store: 16, 8 or 4 bytes
+template <typename T, int VW> struct po_vec;
+template <> struct po_vec<float, 4> { typedef po_f4v type; };
+template <> struct po_vec<float, 2> { typedef po_f2v type; };
+template <> struct po_vec<float, 1> { typedef float type; };
+template <> struct po_vec<double, 2> { typedef po_d2v type; };
+template <> struct po_vec<double, 1> { typedef double type; };
 
-// A TR x TC piece of the scratch (row stride STRIDE floats) that lies inside its block, as stores of VW floats: a row of the piece in
-// the matrix is WIDTH / VW lanes, a wave instruction covers 64 VW / WIDTH rows (VW = 4, WIDTH = 128: two rows, 16-byte stores of 512-byte
-// pieces).  `dst` = the matrix entry of (row 0, column 0) of the piece; TRANSPOSED = false: the piece as it lies in the scratch (TR rows
-// of TC entries), true: its transpose (TC rows of TR entries: the rows of the piece are columns of the scratch).
-template <int NW, int TR, int TC, int STRIDE, int VW, bool TRANSPOSED>
-__device__ __forceinline__ void po_store_piece_f32(float* dst, uint64_t ld, uint32_t wave, uint32_t lane, const float* tl) {
-    typedef typename po_f32_vec<VW>::type vec;
+// A TR x TC piece of the scratch (entries of type T, row stride STRIDE entries) that lies inside its block, as stores of VW entries: a row
+// of the piece in the matrix is WIDTH / VW lanes, a wave instruction covers 64 VW / WIDTH rows (float, VW = 4, WIDTH = 128: two rows,
+// 16-byte stores of 512-byte pieces).  `dst` = the matrix entry of (row 0, column 0) of the piece; TRANSPOSED = false: the piece as it
+// lies in the scratch (TR rows of TC entries), true: its transpose (TC rows of TR entries: the rows of the piece are columns of the scratch).
+template <typename T, int NW, int TR, int TC, int STRIDE, int VW, bool TRANSPOSED>
+__device__ __forceinline__ void po_store_piece(T* dst, uint64_t ld, uint32_t wave, uint32_t lane, const T* tl) {
+    typedef typename po_vec<T, VW>::type vec;
     constexpr int WIDTH = TRANSPOSED ? TR : TC, NROWS = TRANSPOSED ? TC : TR;        // shape of the piece in the matrix
     constexpr int LPR = WIDTH / VW;                                  // lanes per row
     if constexpr (LPR <= 64) {
@@ -231,7 +233,7 @@ __device__ __forceinline__ void po_store_piece_f32(float* dst, uint64_t ld, uint
         static_assert(IT >= 1 && IT * RPI * NW == NROWS, "the waves share the rows of a piece evenly");
         const uint32_t q = lane / LPR, m = lane % LPR;
         const uint32_t r0 = RPI * (wave & (NW - 1)) + q;
-        float* out = dst + (uint64_t)r0 * ld + VW * m;
+        T* out = dst + (uint64_t)r0 * ld + VW * m;
         const uint64_t step = (uint64_t)RPI * NW * ld;
         vec v[IT];
         // (all LDS reads of the wave first, then its stores; the wave index is known to be below NW, so the trip count is fixed)
@@ -239,12 +241,13 @@ __device__ __forceinline__ void po_store_piece_f32(float* dst, uint64_t ld, uint
         for (int it = 0; it < IT; ++it) {
             const uint32_t r = r0 + it * RPI * NW;
             if constexpr (!TRANSPOSED) {
-                const float* src = tl + r * STRIDE + VW * m;
-                if constexpr (VW == 4) { const float2 a = *reinterpret_cast<const float2*>(src), b = *reinterpret_cast<const float2*>(src + 2); v[it] = vec{a.x, a.y, b.x, b.y}; }
-                else if constexpr (VW == 2) { const float2 a = *reinterpret_cast<const float2*>(src); v[it] = vec{a.x, a.y}; }
+                const T* src = tl + r * STRIDE + VW * m;
+                if constexpr (sizeof(T) == 4 && VW == 4) { const float2 a = *reinterpret_cast<const float2*>(src), b = *reinterpret_cast<const float2*>(src + 2); v[it] = vec{a.x, a.y, b.x, b.y}; }
+                else if constexpr (sizeof(T) == 4 && VW == 2) { const float2 a = *reinterpret_cast<const float2*>(src); v[it] = vec{a.x, a.y}; }
+                else if constexpr (VW == 2) v[it] = vec{src[0], src[1]};
                 else v[it] = src[0];
             } else {
-                const float* src = tl + VW * m * STRIDE + r;
+                const T* src = tl + VW * m * STRIDE + r;
                 if constexpr (VW == 4) v[it] = vec{src[0], src[STRIDE], src[2 * STRIDE], src[3 * STRIDE]};
                 else if constexpr (VW == 2) v[it] = vec{src[0], src[STRIDE]};
                 else v[it] = src[0];
@@ -252,15 +255,15 @@ __device__ __forceinline__ void po_store_piece_f32(float* dst, uint64_t ld, uint
         }
 #pragma unroll
         for (int it = 0; it < IT; ++it) __builtin_nontemporal_store(v[it], reinterpret_cast<vec*>(out + it * step));
-    } else {                                                          // 128 single floats per row: two instructions per row
-        static_assert(WIDTH == 128, "single floats: 64 or 128 per row");
-        constexpr int IT = NROWS / NW, GRP = IT < 8 ? IT : 8;         // (eight rows of reads, then their stores: 16 registers)
+    } else {                                                          // 128 single entries per row: two instructions per row
+        static_assert(WIDTH == 128 && VW == 1, "single entries: 64 or 128 per row");
+        constexpr int IT = NROWS / NW, GRP = IT < 8 ? IT : 8;         // (eight rows of reads, then their stores)
         const uint32_t r0 = wave & (NW - 1);
-        float* out = dst + (uint64_t)r0 * ld + lane;
+        T* out = dst + (uint64_t)r0 * ld + lane;
         const uint64_t step = (uint64_t)NW * ld;
 #pragma unroll 1
         for (int g = 0; g < IT; g += GRP) {
-            float v[GRP][2];
+            T v[GRP][2];
 #pragma unroll
             for (int it = 0; it < GRP; ++it) {
                 const uint32_t r = r0 + (g + it) * NW;
@@ -277,40 +280,43 @@ __device__ __forceinline__ void po_store_piece_f32(float* dst, uint64_t ld, uint
     }
 }
 
-// The widest store a piece allows: 4 floats when its rows start on 16-byte boundaries, 2 on 8-byte boundaries, else single floats
-__device__ __forceinline__ int po_f32_store_width(const void* base, uint64_t ld, uint64_t first) {
+// The widest store a piece allows, in entries: 16 bytes when its rows start on 16-byte boundaries, 8 bytes on 8-byte boundaries, else
+// (float only) single entries
+template <typename T>
+__device__ __forceinline__ int po_store_width(const void* base, uint64_t ld, uint64_t first) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(base);
-    if ((ld & 3) == 0 && (first & 3) == 0 && (a & 15) == 0) return 4;
-    if ((ld & 1) == 0 && (first & 1) == 0 && (a & 7) == 0) return 2;
+    constexpr uint32_t per16 = 16 / sizeof(T), per8 = 8 / sizeof(T);
+    if ((ld % per16) == 0 && (first % per16) == 0 && (a & 15) == 0) return (int)per16;
+    if ((ld % per8) == 0 && (first % per8) == 0 && (a & 7) == 0) return (int)per8;
     return 1;
 }
 
 // All NW waves of the workgroup call this after the values sit in `tl` and a barrier has made them visible.  The scratch holds TR rows
-// (i0 ..) of TC columns (j0 ..) of the tile, row stride STRIDE: the whole 128 x 128 tile, its upper or lower half (TR = 64: a kernel that
-// keeps half the scratch - 33 KiB - and makes two passes; its transposed rows then leave as 256-byte pieces) or its left or right half
-// (TC = 64, stride 66: the rows themselves leave as 256-byte pieces).  Tiles inside their block go out without a per-lane test, as
-// 16-byte stores when the rows of the matrix start on 16-byte boundaries (a leading dimension that is a multiple of 4 entries; of 32
-// entries = whole 128-byte lines is better still, and is what this library's own buffers have), as 8- or 4-byte stores otherwise.
-template <int NW, int TR = 128, int TC = 128, int STRIDE = kF32TileStride>
-__device__ __forceinline__ void po_store_tile_f32(const po_tile_args& A, bool mirrors, uint64_t i0, uint64_t j0, uint32_t wave,
-                                                  uint32_t lane, const float* tl) {
-    static_assert((TR == 128 || TR == 64) && (TC == 128 || TC == 64) && STRIDE >= TC && STRIDE % 2 == 0, "whole tiles or halves");
-    float* out = static_cast<float*>(A.out);
+// (i0 ..) of TC columns (j0 ..) of the tile, row stride STRIDE entries of type T (the output type): the whole 128 x 128 tile, a band of
+// its rows (TR = 64 or 32: a kernel that keeps a part of the scratch and makes several passes; its transposed rows then leave as shorter
+// pieces) or its left or right half (TC = 64).  Tiles inside their block go out without a per-lane test, as 16-byte stores when the rows
+// of the matrix start on 16-byte boundaries (float32: a leading dimension that is a multiple of 4 entries; of 32 entries = whole
+// 128-byte lines is better still, and is what this library's own buffers have), as 8- or 4-byte stores otherwise.
+template <typename T, int NW, int TR, int TC, int STRIDE>
+__device__ __forceinline__ void po_store_tile(const po_tile_args& A, bool mirrors, uint64_t i0, uint64_t j0, uint32_t wave,
+                                              uint32_t lane, const T* tl) {
+    static_assert((TR == 128 || TR == 64 || TR == 32) && (TC == 128 || TC == 64) && STRIDE >= TC && STRIDE % 2 == 0, "whole tiles or parts");
+    T* out = static_cast<T*>(A.out);
     const uint64_t n_rows = min(A.row_end, A.n), n_cols = min(A.col_end, A.n);
     const bool inside = i0 >= A.row_begin && i0 + TR <= n_rows && j0 >= A.col_begin && j0 + TC <= n_cols;   // uniform
+    constexpr int VMAX = 16 / sizeof(T);
     // ---- the rows themselves ----
     if (inside) {
-        float* dst = out + (i0 - A.row_begin) * A.ld_out + (j0 - A.col_begin);
-        const int vw = po_f32_store_width(A.out, A.ld_out, j0 - A.col_begin);
-        if (vw == 4) po_store_piece_f32<NW, TR, TC, STRIDE, 4, false>(dst, A.ld_out, wave, lane, tl);
-        else if (vw == 2) po_store_piece_f32<NW, TR, TC, STRIDE, 2, false>(dst, A.ld_out, wave, lane, tl);
-        else if constexpr (TC == 128) po_store_piece_f32<NW, TR, TC, STRIDE, 1, false>(dst, A.ld_out, wave, lane, tl);
-        else po_store_piece_f32<NW, TR, TC, STRIDE, 1, false>(dst, A.ld_out, wave, lane, tl);
+        T* dst = out + (i0 - A.row_begin) * A.ld_out + (j0 - A.col_begin);
+        const int vw = po_store_width<T>(A.out, A.ld_out, j0 - A.col_begin);
+        if (vw == VMAX) po_store_piece<T, NW, TR, TC, STRIDE, VMAX, false>(dst, A.ld_out, wave, lane, tl);
+        else if (vw == VMAX / 2) po_store_piece<T, NW, TR, TC, STRIDE, VMAX / 2, false>(dst, A.ld_out, wave, lane, tl);
+        else if constexpr (VMAX == 4) po_store_piece<T, NW, TR, TC, STRIDE, 1, false>(dst, A.ld_out, wave, lane, tl);
     } else {
         for (uint32_t r = wave; r < TR; r += NW) {
             const uint64_t i = i0 + r;
             if (i < A.row_begin || i >= n_rows) continue;
-            float* row = out + (i - A.row_begin) * A.ld_out;
+            T* row = out + (i - A.row_begin) * A.ld_out;
 #pragma unroll
             for (uint32_t c = lane; c < TC; c += 64) {
                 const uint64_t j = j0 + c;
@@ -320,18 +326,18 @@ __device__ __forceinline__ void po_store_tile_f32(const po_tile_args& A, bool mi
     }
     if (!mirrors) return;
     // ---- the transposed rows (columns of tl) ----
-    float* mir = static_cast<float*>(A.mirror);
+    T* mir = static_cast<T*>(A.mirror);
     if (inside) {
-        float* dst = mir + (j0 - A.col_begin) * A.ld_mirror + (i0 - A.row_begin);
-        const int vw = po_f32_store_width(A.mirror, A.ld_mirror, i0 - A.row_begin);
-        if (vw == 4) po_store_piece_f32<NW, TR, TC, STRIDE, 4, true>(dst, A.ld_mirror, wave, lane, tl);
-        else if (vw == 2) po_store_piece_f32<NW, TR, TC, STRIDE, 2, true>(dst, A.ld_mirror, wave, lane, tl);
-        else po_store_piece_f32<NW, TR, TC, STRIDE, 1, true>(dst, A.ld_mirror, wave, lane, tl);
+        T* dst = mir + (j0 - A.col_begin) * A.ld_mirror + (i0 - A.row_begin);
+        const int vw = po_store_width<T>(A.mirror, A.ld_mirror, i0 - A.row_begin);
+        if (vw == VMAX) po_store_piece<T, NW, TR, TC, STRIDE, VMAX, true>(dst, A.ld_mirror, wave, lane, tl);
+        else if (vw == VMAX / 2) po_store_piece<T, NW, TR, TC, STRIDE, VMAX / 2, true>(dst, A.ld_mirror, wave, lane, tl);
+        else if constexpr (VMAX == 4) po_store_piece<T, NW, TR, TC, STRIDE, 1, true>(dst, A.ld_mirror, wave, lane, tl);
     } else {
         for (uint32_t c = wave; c < TC; c += NW) {
             const uint64_t j = j0 + c;
             if (j < A.col_begin || j >= n_cols) continue;
-            float* row = mir + (j - A.col_begin) * A.ld_mirror;
+            T* row = mir + (j - A.col_begin) * A.ld_mirror;
 #pragma unroll
             for (uint32_t r = lane; r < TR; r += 64) {
                 const uint64_t i = i0 + r;
@@ -339,6 +345,13 @@ __device__ __forceinline__ void po_store_tile_f32(const po_tile_args& A, bool mi
             }
         }
     }
+}
+
+// the float32 form by its round-5 name
+template <int NW, int TR = 128, int TC = 128, int STRIDE = kF32TileStride>
+__device__ __forceinline__ void po_store_tile_f32(const po_tile_args& A, bool mirrors, uint64_t i0, uint64_t j0, uint32_t wave,
+                                                  uint32_t lane, const float* tl) {
+    po_store_tile<float, NW, TR, TC, STRIDE>(A, mirrors, i0, j0, wave, lane, tl);
 }
 
 // ---- register-block epilogue of the VALU tile kernels -------------------------------------------------

@@ -30,12 +30,12 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], "**", "*.db"), recursive=Tru
     for name, counter, val in c.execute("select kernel_name, counter_name, max(value) from counters_collection group by kernel_name, counter_name"):
         vals[short(name)][counter] = val
 KEYS = {"jsd_lut_rows_kernel<double, 16>": "jsd_lut_rows_kernel", "valu_tile_kernel<1, double, 4>": "valu_tile_kernel<JSD>",
-        "valu_tile_kernel<3, double, 8>": "valu_tile_kernel<BC>", "gram_i8_tile_kernel<1, 0, double>": "gram_i8_tile_kernel<1>",
+        "valu_tile_kernel<3, double, 8>": "valu_tile_kernel<BC>", "gram_i8_quad_kernel<0, double>": "gram_i8_quad_kernel<f64>",
         "gram_tile_kernel<0, double>": "gram_tile_kernel<f64>", "bc_sad_tile_kernel<double>": "bc_sad_tile_kernel",
         "pairdot_tile_kernel<1, 0, double>": "pairdot_tile_kernel<KT>", "pairdot_tile_kernel<1, 1, double>": "pairdot_tile_kernel<BC>",
-        "gram_i8_tile_kernel<2, 4, double>": "gram_i8_tile_kernel<2,SC>", "gram_i8_tile_kernel<2, 0, double>": "gram_i8_tile_kernel<2>",
-        "gram_i8_quad_kernel<0>": "gram_i8_quad_kernel<f32>", "gram_i8_half_kernel<0>": "gram_i8_half_kernel<f32>",
-        "gram_i8_half_kernel<4>": "gram_i8_half_kernel<SC,f32>", "bc_sad_tile_kernel<float>": "bc_sad_tile_kernel<f32>"}
+        "gram_i8_half_kernel<4, double>": "gram_i8_half_kernel<SC,f64>", "gram_i8_half_kernel<0, double>": "gram_i8_half_kernel<f64>",
+        "gram_i8_quad_kernel<0, float>": "gram_i8_quad_kernel<f32>", "gram_i8_half_kernel<0, float>": "gram_i8_half_kernel<f32>",
+        "gram_i8_half_kernel<4, float>": "gram_i8_half_kernel<SC,f32>", "bc_sad_tile_kernel<float>": "bc_sad_tile_kernel<f32>"}
 summary = {}
 print("%-44s %10s %9s %9s %9s %9s %12s %10s" % ("kernel", "GUI cyc/8", "VALU %", "LDSissue%", "LDSpipe %", "MFMA %", "LDS confl %", "waves"))
 for k, v in sorted(vals.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):

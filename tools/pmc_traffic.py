@@ -29,14 +29,14 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], "**", "*.db"), recursive=Tru
         vals[short(name)][counter] = val
 N, PAIRS = 50000, 50000 * 49999 / 2.0
 # kernel -> (key of traffic.json = "<metric>_n<N>_d<dim>" as bench.py looks it up, word-space size used for the algorithmic bytes)
-KEYS = {"jsd_lut_rows_kernel<double, 16>": ("JSD_n50000_d256", 256), "gram_i8_tile_kernel<1, 0, double>": ("Eucl_n50000_d256", 256),
+KEYS = {"jsd_lut_rows_kernel<double, 16>": ("JSD_n50000_d256", 256), "gram_i8_quad_kernel<0, double>": ("Eucl_n50000_d256", 256),
         "gram_tile_kernel<0, double>": ("Eucl_f64_n50000_d256", 256), "pairdot_tile_kernel<1, 0, double>": ("KT_n50000_d256", 256),
         "pairdot_tile_kernel<1, 1, double>": ("BC_n50000_d4096", 4096), "valu_tile_kernel<1, double, 4>": ("JSD_ragged_n50000_d256", 256),
-        "valu_tile_kernel<3, double, 8>": ("BC_ragged_n50000_d256", 256), "gram_i8_tile_kernel<2, 0, double>": ("Eucl_ragged_n50000_d256", 256),
-        "bc_sad_tile_kernel<double>": ("BC_sad_n50000", 4096), "gram_i8_tile_kernel<2, 4, double>": ("SC_n50000_d256", 256),
+        "valu_tile_kernel<3, double, 8>": ("BC_ragged_n50000_d256", 256), "gram_i8_half_kernel<0, double>": ("Eucl_ragged_n50000_d256", 256),
+        "bc_sad_tile_kernel<double>": ("BC_sad_n50000", 4096), "gram_i8_half_kernel<4, double>": ("SC_n50000_d256", 256),
         # float32 matrices (round 5): 8 bytes of output per pair
-        "gram_i8_quad_kernel<0>": ("Eucl_f32_n50000_d256", 256, 8.0), "gram_i8_half_kernel<0>": ("Eucl_f32_ragged_n50000_d256", 256, 8.0),
-        "gram_i8_half_kernel<4>": ("SC_f32_n50000_d256", 256, 8.0), "bc_sad_tile_kernel<float>": ("BC_sad_f32_n50000_d256", 256, 8.0)}
+        "gram_i8_quad_kernel<0, float>": ("Eucl_f32_n50000_d256", 256, 8.0), "gram_i8_half_kernel<0, float>": ("Eucl_f32_ragged_n50000_d256", 256, 8.0),
+        "gram_i8_half_kernel<4, float>": ("SC_f32_n50000_d256", 256, 8.0), "bc_sad_tile_kernel<float>": ("BC_sad_f32_n50000_d256", 256, 8.0)}
 _ver, _hash = lib_identity()
 out = {"_detail": {"how": __doc__.split("usage:")[0].strip(), "source": sys.argv[2], "lib_version": _ver, "src_hash": _hash}}
 print("%-46s %14s %16s %14s %14s %8s" % ("kernel (largest dispatch)", "FETCH_SIZE KiB", "fetch B (x2)", "WRITE_SIZE KiB", "traffic B", "/ algo"))
