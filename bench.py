@@ -285,6 +285,8 @@ def main():
                                                              "number of contigs through every metric)")
     ap.add_argument("--no-complete-rows", action="store_true", help="N>1: skip timing the optional row-completing exchange")
     ap.add_argument("--no-path-lines", action="store_true", help="skip config.path_lines (H2D, D2H, container write, end-to-end CLI wall)")
+    ap.add_argument("--complete-rows-timeout", type=float, default=300.0,
+                    help="seconds the optional row-completing exchange of an N > 1 run may take before the record is printed without it")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("PO_BENCH_LAUNCH_TIMEOUT", "3000")),
                     help="--gpus N>1 started plainly: seconds after which the launcher kills its ranks")
     args = ap.parse_args()
@@ -420,16 +422,6 @@ def main():
         g = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(dist.get_world_size())]
         dist.all_gather(g, torch.tensor([kernel_ms], dtype=torch.float64, device=cdev))
         rank_kernel_ms = [float(x.item()) for x in g]
-        if not args.no_complete_rows and not rehearsal and world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            plan.complete_rows(rank, slab, mirrors, dist)
-            torch.cuda.synchronize(dev)
-            dist.barrier()
-            t = torch.tensor([(time.perf_counter() - t0) * 1e3], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            complete_rows_ms = float(t.item())
 
     pairs = n * (n - 1) / 2.0
     ms_per_step = elapsed / args.steps * 1e3
@@ -711,6 +703,45 @@ def main():
                     "note": "host pointers in, host float64 matrix out (H2D, kernels, D2H), best of 3; matrix %s" % (m1.shape,)}
             except Exception as exc:             # never let the extras break the headline line
                 result["cpu_baseline"]["c1_full"]["same_job_on_the_gpu"] = {"error": repr(exc)}
+    # The optional second exchange (mirror blocks to their row owners: point to point over RCCL, never run on more than one GPU
+    # so far) comes LAST, behind a watchdog: if it does not complete, rank 0 still prints the record - whose `value` does not
+    # depend on it - with the failure named, and every rank leaves.
+    if dist is not None and world > 1 and not args.no_complete_rows:
+        import threading
+        finished = threading.Event()
+
+        def watchdog():
+            if finished.wait(args.complete_rows_timeout):
+                return
+            if rank == 0:
+                result["config"]["multi_gpu"]["complete_rows_error"] = "no completion within %g s; the ranks left without it" % args.complete_rows_timeout
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            if rehearsal:                        # gloo moves host tensors; the slab stays on the device
+                plan.complete_rows(rank, slab, [None if m is None else m.cpu() for m in mirrors], dist, stage_device="cpu")
+            else:
+                plan.complete_rows(rank, slab, mirrors, dist)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t = torch.tensor([(time.perf_counter() - t0) * 1e3], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if rank == 0:
+                result["config"]["multi_gpu"]["complete_rows_ms"] = float(t.item())
+        except Exception as exc:                 # noqa: BLE001 - the record goes out whatever this optional step does
+            if rank == 0:
+                result["config"]["multi_gpu"]["complete_rows_error"] = repr(exc)[:400]
+            finished.set()
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            os._exit(0)                          # a failed collective leaves the group unusable: no barrier, no destroy
+        finished.set()
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

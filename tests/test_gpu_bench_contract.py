@@ -73,6 +73,25 @@ def test_bench_multi_rank_path_rehearsal():
     assert mg["kernel_ms_min"] <= mg["kernel_ms_max"] and mg["allgather_bytes"] == 4096 * 256 * 4 + 4096 * 8
     assert r["config"]["env_knobs"].get("PO_BENCH_REHEARSAL") == "1"
     assert abs(r["value"] - r["config"]["pairs"] / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+    assert mg["complete_rows_ms"] > 0 and "complete_rows_error" not in mg      # the optional exchange, behind the record
+
+
+def test_bench_record_survives_an_exchange_that_does_not_complete():
+    """The row-completing exchange of an N > 1 run is optional and has never met a second GPU: it runs last, behind a watchdog.
+    With a timeout it cannot meet (1 ms) rank 0 prints the record - `value` and all - with the failure named, and the ranks leave."""
+    env = dict(os.environ, PO_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--contigs", "4096", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--complete-rows-timeout", "0.001"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    mg = r["config"]["multi_gpu"]
+    # (rank 0's own watchdog, or its collective failing because the other rank's watchdog was first)
+    assert r["n_gpus"] == 2 and r["value"] > 0 and mg["complete_rows_ms"] is None and mg["complete_rows_error"]
 
 
 def test_bench_launches_its_own_ranks():
