@@ -200,24 +200,33 @@ __device__ __forceinline__ double gram_i8_value(const double G, const double t0r
     }
 }
 
-// The same values without their rare cases, N pairs at a time and step by step across the N (no branch, no load): bit i of the
-// result is set where gram_i8_value has to be asked instead - a squared distance at cancellation level (or exactly 0: the square
-// root below has no zero guard), identical rank vectors.  A branch per pair keeps every pair's ~20 dependent float64
+// The same values without their rare cases, N pairs at a time and step by step across the N (no branch, no load).  The result is
+// the OR of the wave masks of the lanes where gram_i8_value has to be asked instead - a squared distance at cancellation level
+// (or 0, or rounded below 0: the square root below has neither a clamp nor a zero guard), identical rank vectors - kept in scalar
+// registers: it costs the vector ALU one comparison per pair.  A branch per pair keeps every pair's ~20 dependent float64
 // instructions in a basic block of their own; written like this, N independent chains are in flight in one wave, which is what
-// two waves per SIMD need to keep the vector ALU busy (the persistent variant of round 5, and any kernel at low occupancy).  Where its bit is clear a result equals
-// gram_i8_value's bit for bit.
+// two waves per SIMD need to keep the vector ALU busy.  Where a lane's bit is clear its result equals gram_i8_value's bit for bit.
+//   Eucl: gram_i8_value's test is  max(x, 0) <= 1e-13 sum.  Here (end of round 5: the clamp, the product and the float64 comparison
+//   were 3 of ~17 float64-rate instructions per pair - 29.7 -> 27.7 ms at 200 000 records without them) the HIGH WORDS are compared:
+//   for doubles 0 <= a <= b the high words are ordered the same way as integers, and so are they read as float32 (the patterns are
+//   far from that format's NaNs), a negative x reads as a negative float32; 2^-43 > 1e-13, so
+//       hi(x) <=_f32 hi(sum) - (43 << 20)
+//   holds for every pair the exact test holds for and a few more just above it (sum is 0 or >= 2^-64: S >= 1, totals < 2^32); the
+//   subtraction saturates at 0, which is the case sum = 0 = x of two empty records.
 template <int METRIC, int N, typename OUT>
-__device__ __forceinline__ uint32_t gram_i8_values_fast(const double (&G)[N], const double (&t0r)[N], const double (&t1r)[N],
-                                                        const double (&t0c)[N], const double (&t1c)[N], OUT (&out)[N]) {
-    uint32_t special = 0;
+__device__ __forceinline__ unsigned long long gram_i8_values_fast(const double (&G)[N], const double (&t0r)[N], const double (&t1r)[N],
+                                                                  const double (&t0c)[N], const double (&t1c)[N], OUT (&out)[N]) {
+    unsigned long long special = 0;
     double x[N], y[N];
     if (METRIC == PO_EUCL) {
         double gg[N], h[N], r[N];
 #pragma unroll
         for (int e = 0; e < N; ++e) {
             const double sum = t0r[e] + t0c[e];
-            x[e] = fmax(fma(G[e], (-2.0 * t1r[e]) * t1c[e], sum), 0.0);
-            special |= (x[e] <= 1.0e-13 * sum) ? (1u << e) : 0u;
+            x[e] = fma(G[e], (-2.0 * t1r[e]) * t1c[e], sum);
+            uint32_t thr;
+            asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(thr) : "v"((uint32_t)__double2hiint(sum)), "s"(43u << 20));
+            special |= __builtin_amdgcn_ballot_w64(__uint_as_float((uint32_t)__double2hiint(x[e])) <= __uint_as_float(thr));
         }
 #pragma unroll
         for (int e = 0; e < N; ++e) y[e] = __builtin_amdgcn_rsq(x[e]);      // po_sqrt_nonneg without its x == 0 case
@@ -233,7 +242,7 @@ __device__ __forceinline__ uint32_t gram_i8_values_fast(const double (&G)[N], co
         for (int e = 0; e < N; ++e) out[e] = (OUT)fma(r[e], h[e], gg[e]);
     } else {
 #pragma unroll
-        for (int e = 0; e < N; ++e) { x[e] = t0r[e] * t0c[e]; special |= (G[e] == t0r[e] && G[e] == t0c[e]) ? (1u << e) : 0u; }
+        for (int e = 0; e < N; ++e) { x[e] = t0r[e] * t0c[e]; special |= __builtin_amdgcn_ballot_w64(G[e] == t0r[e] && G[e] == t0c[e]); }
 #pragma unroll
         for (int e = 0; e < N; ++e) y[e] = __builtin_amdgcn_rsq(x[e]);
 #pragma unroll
@@ -243,7 +252,7 @@ __device__ __forceinline__ uint32_t gram_i8_values_fast(const double (&G)[N], co
 #pragma unroll
         for (int e = 0; e < N; ++e) out[e] = (OUT)(1.0 - G[e] * y[e]);
     }
-    asm volatile("" : "+v"(special));                      // the comparisons are made here, not collected at the end of the caller
+    asm volatile("" : "+s"(special));                      // the comparisons are made here, not collected at the end of the caller
     return special;
 }
 
@@ -275,7 +284,7 @@ __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1
         for (int s = NG - 2; s >= 0; --s) G = fma(128.0, G, (double)g[s][nn][reg]);
         return G;
     };
-    uint32_t special = 0;
+    unsigned long long special = 0;                        // wave masks of the lanes with a rare case (scalar registers)
 #pragma unroll
     for (int r0 = REG0; r0 < REG0 + NREG; r0 += kIlpRows) {
         double G[2 * kIlpRows], a0[2 * kIlpRows], a1[2 * kIlpRows], b0[2 * kIlpRows], b1[2 * kIlpRows];
@@ -297,7 +306,7 @@ __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1
             b1[2 * e] = ic0; b1[2 * e + 1] = ic1;
         }
         special |= gram_i8_values_fast<METRIC, 2 * kIlpRows, OUT>(G, a0, a1, b0, b1, v);
-        asm volatile("" : "+v"(special));                  // one running word, not sixteen partial ones kept for a tree of ORs
+        asm volatile("" : "+s"(special));                  // one running mask, not sixteen partial ones kept for a tree of ORs
 #pragma unroll
         for (int e = 0; e < kIlpRows; ++e) {
             const int reg = r0 + e;
@@ -308,7 +317,7 @@ __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1
         __builtin_amdgcn_sched_barrier(0);
     }
     // the rare cases, wave by wave: a pair at cancellation level somewhere in the wave's block, or the diagonal of the matrix
-    if (diag_tile || __builtin_amdgcn_ballot_w64(special != 0) != 0) {
+    if (diag_tile || special != 0) {
         // (everything is derived again from the accumulators, behind a barrier the compiler cannot see through: values shared
         //  with the straight-line pass above would stay live across it - 32 Gram entries and 32 row terms are 128 registers)
         asm volatile("" ::: "memory");
