@@ -179,15 +179,38 @@ __device__ __forceinline__ double gram_i8_value(const double G, const double t0r
     if (METRIC == PO_EUCL) {
         const double sum = t0r + t0c;
         double d2 = fmax(fma(G, (-2.0 * t1r) * t1c, sum), 0.0);
-        if (d2 <= 1.0e-13 * sum) {
-            // cancellation level: are the two count vectors proportional, i.e. the frequency vectors identical
-            // (distance exactly 0 in the reference)?  Cauchy-Schwarz equality G^2 == S_r S_c, tested exactly
-            // with error-free products (all three are integers below 2^53).
+        double scale = 1.0;
+        if (d2 <= 0x1p-21 * sum) {
+            // cancellation level.  (1) Are the two count vectors proportional, i.e. the frequency vectors identical (distance exactly 0 in
+            // the reference)?  Cauchy-Schwarz equality G^2 == S_r S_c, tested exactly with error-free products (all three are integers
+            // below 2^53).  (2) Otherwise the three rounded terms above have lost their leading bits to each other - at d^2 = 1e-11 sum the
+            // distance is good to 2e-6 only, found by a fuzz seed with two near-identical records at the end of round 5 - and the squared
+            // distance is taken from the integers instead:  d^2 = N / (n_r n_c)^2,  N = S_r n_c^2 + S_c n_r^2 - 2 G n_r n_c  = |n_c a - n_r b|^2,
+            // in double-double arithmetic (error-free products and sums; every factor an exact integer, the totals recovered from their
+            // rounded reciprocals), so that N keeps ~50 bits after a cancellation of 2^-50.  Symmetric in the two records like the form above.
             const double sr = *t2r, sc = *t2c;
             const double p = G * G, pe = fma(G, G, -p), q = sr * sc, qe = fma(sr, sc, -q);
-            if (p == q && pe == qe) d2 = 0.0;
+            if (p == q && pe == qe) {
+                d2 = 0.0;
+            } else if (t1r > 0.0 && t1c > 0.0) {
+                // (one product at a time, so that few values are live at once: the two-plane kernels run this next to 96 accumulators)
+                double nc = __builtin_amdgcn_rcp(t1c);                            // totals < 2^32: reciprocal of the rounded reciprocal,
+                nc = rint(fma(fma(-t1c, nc, 1.0), nc, nc));                       // one Newton step, rounds back to the integer
+                double h = nc * nc, l = fma(nc, nc, -h);                          // n_c^2 < 2^64, exact as a pair
+                const double ah = sr * h, al = fma(sr, h, -ah) + sr * l;          // S_r n_c^2
+                double nr = __builtin_amdgcn_rcp(t1r);
+                nr = rint(fma(fma(-t1r, nr, 1.0), nr, nr));
+                h = nr * nr; l = fma(nr, nr, -h);
+                const double bh = sc * h, bl = fma(sc, h, -bh) + sc * l;          // S_c n_r^2
+                const double s1 = ah + bh, v1 = s1 - ah, e1 = ((ah - (s1 - v1)) + (bh - v1)) + (al + bl);
+                h = nr * nc; l = fma(nr, nc, -h);
+                const double g2 = 2.0 * G, ch = g2 * h, cl = fma(g2, h, -ch) + g2 * l;   // 2 G n_r n_c
+                const double s2 = s1 - ch, v2 = s2 - s1, e2 = ((s1 - (s2 - v2)) + (-ch - v2)) + (e1 - cl);
+                d2 = fmax(s2 + e2, 0.0);
+                scale = t1r * t1c;                                                // 1 / (n_r n_c): d = sqrt(N) / (n_r n_c)
+            }
         }
-        const double v = po_sqrt_nonneg(d2);
+        const double v = po_sqrt_nonneg(d2) * scale;
         return same ? 0.0 : v;
     } else {                                               // SC; a constant record has N = 0 -> NaN as SciPy gives
         // G / sqrt(N_r N_c) as G * rsqrt: v_rsq_f64 seed + two Newton steps (~1 ulp) instead of the
@@ -206,11 +229,11 @@ __device__ __forceinline__ double gram_i8_value(const double G, const double t0r
 // registers: it costs the vector ALU one comparison per pair.  A branch per pair keeps every pair's ~20 dependent float64
 // instructions in a basic block of their own; written like this, N independent chains are in flight in one wave, which is what
 // two waves per SIMD need to keep the vector ALU busy.  Where a lane's bit is clear its result equals gram_i8_value's bit for bit.
-//   Eucl: gram_i8_value's test is  max(x, 0) <= 1e-13 sum.  Here (end of round 5: the clamp, the product and the float64 comparison
+//   Eucl: gram_i8_value's test is  max(x, 0) <= 2^-21 sum.  Here (end of round 5: the clamp, the product and the float64 comparison
 //   were 3 of ~17 float64-rate instructions per pair - 29.7 -> 27.7 ms at 200 000 records without them) the HIGH WORDS are compared:
 //   for doubles 0 <= a <= b the high words are ordered the same way as integers, and so are they read as float32 (the patterns are
-//   far from that format's NaNs), a negative x reads as a negative float32; 2^-43 > 1e-13, so
-//       hi(x) <=_f32 hi(sum) - (43 << 20)
+//   far from that format's NaNs), a negative x reads as a negative float32, so
+//       hi(x) <=_f32 hi(sum) - (20 << 20)
 //   holds for every pair the exact test holds for and a few more just above it (sum is 0 or >= 2^-64: S >= 1, totals < 2^32); the
 //   subtraction saturates at 0, which is the case sum = 0 = x of two empty records.
 template <int METRIC, int N, typename OUT>
@@ -225,7 +248,7 @@ __device__ __forceinline__ unsigned long long gram_i8_values_fast(const double (
             const double sum = t0r[e] + t0c[e];
             x[e] = fma(G[e], (-2.0 * t1r[e]) * t1c[e], sum);
             uint32_t thr;
-            asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(thr) : "v"((uint32_t)__double2hiint(sum)), "s"(43u << 20));
+            asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(thr) : "v"((uint32_t)__double2hiint(sum)), "s"(20u << 20));
             special |= __builtin_amdgcn_ballot_w64(__uint_as_float((uint32_t)__double2hiint(x[e])) <= __uint_as_float(thr));
         }
 #pragma unroll
@@ -331,14 +354,35 @@ __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1
             }
             return G;
         };
+        // (two and three planes: all Gram entries of the block first - a pair of registers each instead of three or five accumulators -
+        //  so that the exact branch of gram_i8_value has room next to them)
+        double Gs[NG >= 3 ? NREG : 1][2];
+        if constexpr (NG >= 3) {
+#pragma unroll
+            for (int reg = REG0; reg < REG0 + NREG; ++reg) {
+                Gs[reg - REG0][0] = gram_again(0, reg);
+                Gs[reg - REG0][1] = gram_again(1, reg);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // (the lane's coordinates once more, and every address from them: nothing per-lane is carried over from the pass above, and the
+        //  column terms are read where they are used)
+        uint32_t lane_c;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_c));
+        const uint32_t lrc = lane_c & 31, lhc = lane_c >> 5;
+        OUT* wtc = tl + (trow + 4 * lhc) * STRIDE + wc * 64 + lrc;
 #pragma unroll
         for (int reg = REG0; reg < REG0 + NREG; ++reg) {
-            const uint32_t rl = (reg & 3) + 8 * ((reg - REG0) >> 2) + 4 * lh;
-            const double trr = t0r[rl], irr = METRIC == PO_EUCL ? t1r[rl] : 0.0;
-            OUT* wp = wt + ((reg & 3) + 8 * ((reg - REG0) >> 2)) * STRIDE;
-            wp[0] = (OUT)gram_i8_value<METRIC>(gram_again(0, reg), trr, irr, t2r + rl, tc0, ic0, t2c + lr, diag_tile && rrow + rl == ccol + lr);
-            wp[32] = (OUT)gram_i8_value<METRIC>(gram_again(1, reg), trr, irr, t2r + rl, tc1, ic1, t2c + 32 + lr, diag_tile && rrow + rl == ccol + 32 + lr);
-            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t rl = (reg & 3) + 8 * ((reg - REG0) >> 2) + 4 * lhc;
+            OUT* wp = wtc + ((reg & 3) + 8 * ((reg - REG0) >> 2)) * STRIDE;
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) {
+                const uint32_t cl = 32 * nn + lrc;
+                const double G = NG >= 3 ? Gs[NG >= 3 ? reg - REG0 : 0][nn] : gram_again(nn, reg);
+                wp[32 * nn] = (OUT)gram_i8_value<METRIC>(G, t0r[rl], METRIC == PO_EUCL ? t1r[rl] : 0.0, t2r + rl, t0c[cl],
+                                                          METRIC == PO_EUCL ? t1c[cl] : 0.0, t2c + cl, diag_tile && rrow + rl == ccol + cl);
+                __builtin_amdgcn_sched_barrier(0);         // (one value after the other: their exact branches are long)
+            }
         }
     }
 }

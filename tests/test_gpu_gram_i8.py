@@ -53,6 +53,43 @@ def test_eucl_digit_planes(ctx, top, kernel, dim):
         assert np.array_equal(f32, got.astype(np.float32))
 
 
+@pytest.mark.parametrize("top,dim", [(100, 4096), (5000, 256), (200_000, 256), (2_000_000, 64), (3_000_000, 64)])
+@pytest.mark.parametrize("n", [300, 8300])
+def test_eucl_near_duplicates_keep_their_relative_accuracy(ctx, top, dim, n):
+    """Records that differ from another by one or a few k-mers: in  S_a/n_a^2 + S_b/n_b^2 - 2 G/(n_a n_b)  the three rounded terms
+    cancel to d^2 / sum = 1e-7 ... 1e-13, and the square root of that was good to 1e-6 ... 1e-5 only (a fuzz seed at the end of
+    round 5: two near-identical records, error 2e-6).  From 2^-21 on the squared distance now comes from the exact integers in
+    double-double arithmetic; the float64 Gram kernel (counts beyond 2 097 151, and table_path=False) sums the squared differences
+    of such a pair word by word, as the reference does.  One, two and three digit planes and the float64 kernel, both sides of the
+    8 192-record switch, float32 = rounded float64, exactly symmetric; against the oracle's direct sum of squared differences
+    (itself good to ~1e-11 here)."""
+    import torch
+    rng = np.random.default_rng(top + dim + n)
+    counts = rng.integers(top // 4, top // 2, size=(n, dim)).astype(np.uint32)
+    counts[0, 0] = top                                       # the plane class of the whole matrix (below 8 192 records) / of block 0
+    near = []
+    for t in range(40):                                      # record 10 + 2 t + 1 = record 10 + 2 t with one to three counts moved by 1 .. 3
+        a, b = 10 + 2 * t, 11 + 2 * t
+        counts[b] = counts[a]
+        for w in rng.integers(0, dim, size=1 + t % 3):
+            counts[b, w] += 1 + t % 3
+        near.append((a, b))
+    totals = counts.astype(np.int64).sum(1)
+    dc, dt = torch.from_numpy(counts.view(np.int32)).cuda(), torch.from_numpy(totals).cuda()
+    got = ctx.pairwise(dc, dt, "Eucl").cpu().numpy()
+    f32 = ctx.pairwise(dc, dt, "Eucl", dtype="float32").cpu().numpy()
+    assert np.array_equal(got, got.T) and np.array_equal(f32, got.astype(np.float32))
+    freq = oracle.counts_to_frequencies(counts.astype(np.int64), totals)
+    want = oracle.pairwise_block(freq, "Eucl", row_begin=10, row_end=90)      # the near-duplicate records against everybody
+    np.testing.assert_allclose(got[10:90], want, rtol=1e-9, atol=1e-300)
+    if n <= 300:                                             # the same through the float64 Gram kernel
+        general = ctx.pairwise(dc, dt, "Eucl", table_path=False).cpu().numpy()
+        np.testing.assert_allclose(general[10:90], want, rtol=1e-7, atol=1e-300)      # (its Gram entries are rounded sums of D products)
+        assert np.array_equal(general, general.T)
+    ratios = [got[a, b] ** 2 / ((freq[a] ** 2).sum() + (freq[b] ** 2).sum()) for a, b in near]
+    assert min(ratios) > 0 and min(ratios) < 2.0 ** -22 and max(ratios) < 1e-5   # the pairs the test is about are at cancellation level
+
+
 @pytest.mark.parametrize("dim", [4096, 16384])
 def test_eucl_three_planes_large_word_space(ctx, dim):
     """Three digit planes at k = 6 / 7: the middle accumulator group adds three digit products per word, so its worst case -
