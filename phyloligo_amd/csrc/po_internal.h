@@ -74,6 +74,7 @@ struct po_ctx {
     uint32_t* h_blockmax = nullptr;    // pinned host copy of the int8 Gram path's largest counts (whole matrix, then per 128-record block)
     size_t h_blockmax_cap = 0;         // in words
     po_buf ws_tilelist;                // per-class tile lists of the int8 Gram path (po_gram_i8.hip)
+    po_buf ws_fix;                     // po_fix_list of the JSD path (po_jsd_exact.hip)
     void* h_stage[2] = {nullptr, nullptr};   // pinned staging buffers of the host-pointer entry points (device -> host rows)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -156,6 +157,17 @@ struct po_tile_args {
     int triangular;         // rows == columns: only tiles on/above the diagonal are computed (mirror = out)
     uint32_t dbl_at;        // word index at which running sums double (reverse-complement folded operands,
                             // po_fold.hip); 0xFFFFFFFF = never.  A multiple of the kernel's staging step.
+    struct po_fix_list* fix;  // JSD: where a wave notes that its rows of a tile hold a value at cancellation level (or NULL)
+};
+// JSD of near-identical records (po_jsd_exact.hip).  1/2 (E_a + E_b - S) subtracts sums of size ln D and is good to ~1e-14 absolute;
+// a wave of a JSD tile kernel whose rows hold a value below 2^-20 appends (tile, first row, rows) here, and a small kernel behind the
+// tile kernels evaluates exactly those values again, word by word in a cancellation-free form.  More entries than the list holds:
+// none is processed (all or nothing, so that a result never depends on the order of the appends).
+#define PO_FIX_CAP 16384u
+#define PO_FIX_BELOW_HI 0x3EB00000u    // high word of 2^-20: v >= 0 is below 2^-20 iff hi(v) < this
+struct po_fix_list {
+    uint32_t count, pad;
+    unsigned long long entry[PO_FIX_CAP];     // ti << 40 | tj << 16 | first row << 8 | rows   (ti, tj < 2^24)
 };
 #define PO_NO_DOUBLING 0xFFFFFFFFu
 #define PO_FOLD_SELFS_FIRST 0xFFFFu    // `gran` value of po_rc_fold selecting the Kendall layout [self-paired | representatives]
@@ -177,6 +189,9 @@ size_t po_jsd_lut_workspace(uint64_t n, uint32_t dim);
 int po_launch_jsd_lut_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
                            uint64_t npad, const double* d_wsum, void* ws, const unsigned long long** cls_out);
 int po_launch_jsd_lut_tiles(po_ctx* ctx, const po_tile_args& a, uint64_t n, const void* ws, uint64_t* tiles);
+// po_jsd_exact.hip: the list the JSD tile kernels append to (emptied), and the pass behind them
+int po_jsd_exact_reset(po_ctx* ctx, po_fix_list** list);
+int po_launch_jsd_exact(po_ctx* ctx, const po_tile_args& a, const uint32_t* d_counts, const uint64_t* d_totals, const double* d_freq, uint32_t dim);
 size_t po_bc_sad_workspace(uint64_t n, uint32_t dim);
 int po_launch_bc_sad_prep(po_ctx* ctx, const uint32_t* d_counts, const uint64_t* d_totals, uint64_t n, uint32_t dim,
                           uint64_t npad, void* ws, const unsigned long long** cls_out);

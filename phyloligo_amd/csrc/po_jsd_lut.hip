@@ -285,13 +285,21 @@ __global__ __launch_bounds__(64 * TM / RW, 4) void jsd_lut_rows_kernel(po_tile_a
         acc[r][0] = fmax(0.5 * (ei + ej0 - fma(acc[r][0], inv_n, -two_ln_n)) + LN2, 0.0);
         acc[r][1] = fmax(0.5 * (ei + ej1 - fma(acc[r][1], inv_n, -two_ln_n)) + LN2, 0.0);
     }
+    // (values at cancellation level - near-identical records - are noted for po_jsd_exact.hip: the smallest high word of the lane's
+    //  values, one integer minimum per pair; the diagonal itself is left out)
+    uint32_t lowhi = 0x7FF00000u;
     if (ti == tj) {                                                              // metric(x, x) / squareform diagonal
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            if (ib + r == jc) acc[r][0] = 0.0;
-            if (ib + r == jc + 1) acc[r][1] = 0.0;
+            if (ib + r == jc) acc[r][0] = 0.0; else lowhi = min(lowhi, (uint32_t)__double2hiint(acc[r][0]));
+            if (ib + r == jc + 1) acc[r][1] = 0.0; else lowhi = min(lowhi, (uint32_t)__double2hiint(acc[r][1]));
         }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            lowhi = min(lowhi, min((uint32_t)__double2hiint(acc[r][0]), (uint32_t)__double2hiint(acc[r][1])));
     }
+    po_fix_note(A.fix, po_fix_hits(lowhi), ti, tj, RW * wv, RW);
     OUT* out = static_cast<OUT*>(A.out);
     OUT* mir = static_cast<OUT*>(A.mirror);
     double* lds = reinterpret_cast<double*>(smem);

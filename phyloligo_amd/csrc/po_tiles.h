@@ -191,6 +191,19 @@ __device__ __forceinline__ void po_store_pair(const po_tile_args& A, uint64_t i,
 
 // a tile writes its transpose iff the block has a mirror target and the tile is not on the diagonal
 // of a triangular block (those tiles are computed in full)
+// JSD tile kernels: `lowhi` = the smallest high word among a lane's values of this tile (>= 0, the diagonal left out); po_fix_hits
+// = the lanes that hold one below 2^-20 (a wave mask, scalar registers).  If any does, one lane appends (tile, first row, rows) to the
+// list of po_jsd_exact.hip.
+__device__ __forceinline__ unsigned long long po_fix_hits(uint32_t lowhi) { return __builtin_amdgcn_ballot_w64(lowhi < PO_FIX_BELOW_HI); }
+__device__ __forceinline__ void po_fix_note(po_fix_list* fix, unsigned long long hit, uint32_t ti, uint32_t tj, uint32_t row0, uint32_t rows) {
+    if (fix == nullptr || hit == 0ull) return;
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(hit)) {
+        const uint32_t at = atomicAdd(&fix->count, 1u);
+        if (at < PO_FIX_CAP)
+            fix->entry[at] = ((unsigned long long)ti << 40) | ((unsigned long long)tj << 16) | ((unsigned long long)row0 << 8) | rows;
+    }
+}
+
 __device__ __forceinline__ bool po_tile_mirrors(const po_tile_args& A, uint32_t ti, uint32_t tj) {
     return A.mirror != nullptr && !(A.triangular && ti == tj);
 }

@@ -232,11 +232,13 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void valu_tile_kernel
         wi[ia] = w2.x; wi[ia + 1] = w2.y;
     }
     const bool mirrors = po_tile_mirrors(A, ti, tj);   // uniform
+    unsigned long long fix_hits = 0;                   // JSD: lanes with a value at cancellation level (po_jsd_exact.hip; a wave mask)
     // one column group at a time: its per-record terms, its values, its stores (po_store_block_part) - then its registers are dead
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const double2 e2 = *reinterpret_cast<const double2*>(e_col + co + 32 * q), w2 = *reinterpret_cast<const double2*>(w_col + co + 32 * q);
         double v[RPT][2];
+        uint32_t lowhi = 0x7FF00000u;                  // the smallest high word of this column group's values
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const double ej = e ? e2.y : e2.x, wj = e ? w2.y : w2.x;
@@ -250,11 +252,14 @@ __global__ __launch_bounds__(2048 / RPT, RPT == 8 ? 2 : 4) void valu_tile_kernel
                     x = acc[ia][2 * q + e] / (wi[ia] + wj);              // 0/0 -> NaN as SciPy gives
                 }
                 if (diag_tile && ro + ia == co + 32 * q + e) x = 0.0;    // metric(x,x) / squareform diagonal
+                else if (METRIC == PO_JSD) lowhi = min(lowhi, (uint32_t)__double2hiint(x));
                 v[ia][e] = x;
             }
         }
+        if (METRIC == PO_JSD) fix_hits |= po_fix_hits(lowhi);
         po_store_block_part<OUT, RPT, NT>(A, mirrors, i0, j0, tx_e, ty_e, q, v, reinterpret_cast<double*>(smem));
     }
+    if (METRIC == PO_JSD) po_fix_note(A.fix, fix_hits, ti, tj, wave_s * (4 * RPT), 4 * RPT);   // a wave = four lane rows of RPT records
 }
 
 template <int METRIC, int RPT>
