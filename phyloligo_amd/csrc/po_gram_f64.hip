@@ -175,12 +175,13 @@ __global__ __launch_bounds__(kThreads, 2) void gram_tile_kernel(po_tile_args A, 
                 if (METRIC == PO_EUCL) {
                     const double sum = ni[m][reg] + nj;
                     double d2 = sum - 2.0 * g;
-                    // Cancellation level (near-identical records; identical ones give d2 == 0 exactly by construction, above): the
+                    // Cancellation level (near-identical records; d2 == 0 included - identical records give it by construction, but so
+                    // does a pair whose distance is below 1e-8 of its norms: an adversarial fuzz found 2.5e-9 returned as 0): the
                     // three rounded terms have lost their leading bits to each other - at d^2 = 1e-11 sum the distance was good to
                     // 2e-6 only (a fuzz seed at the end of round 5).  Such a pair is evaluated the way the reference does it, as the
                     // sum of squared differences over the words (operand matrix in HBM; a rare, divergent loop).  From 2^-16 on: the Gram
                     // entry itself carries the rounding of up to D additions here (4 096 words: 4.5e-13 at worst, 1.5e-8 of a distance at the threshold).
-                    if (d2 != 0.0 && d2 <= 0x1p-16 * sum && i != j && i < A.n && j < A.n) {
+                    if (d2 <= 0x1p-16 * sum && i != j && i < A.n && j < A.n) {
                         const double* pi = A.ft + i;
                         const double* pj = A.ft + j;
                         double acc2 = 0.0;

@@ -90,6 +90,33 @@ def test_eucl_near_duplicates_keep_their_relative_accuracy(ctx, top, dim, n):
     assert min(ratios) > 0 and min(ratios) < 2.0 ** -22 and max(ratios) < 1e-5   # the pairs the test is about are at cancellation level
 
 
+def test_eucl_distance_far_below_the_resolution_of_the_gram_form(ctx):
+    """One word holds most of every record (5e8 of 8e8 k-mers - beyond the int8 planes: the float64 Gram kernel) and two records
+    differ by two k-mers: the distance is 3e-9 of the norms, d^2 / sum = 1e-17 - below what |a|^2 + |b|^2 - 2 a.b can hold at all, it
+    came out as exactly 0 (an adversarial fuzz at the end of round 5).  Such pairs are summed word by word, as the reference does."""
+    import math
+    import torch
+    rng = np.random.default_rng(99)
+    n, dim = 130, 256
+    counts = rng.integers(0, 2_000_000, size=(n, dim)).astype(np.int64)
+    counts[:, 0] += 500_000_000
+    near = [(2 * t, 2 * t + 1) for t in range(20)]
+    for a, b in near:
+        counts[b] = counts[a]
+        w = rng.choice(np.arange(1, dim), size=2, replace=False)
+        counts[b, w[0]] += 1
+        counts[b, w[1]] -= 1 if counts[b, w[1]] > 0 else -1
+    totals = counts.sum(1)
+    got, st = ctx.pairwise(torch.from_numpy(counts.astype(np.int32)).cuda(), torch.from_numpy(totals).cuda(), "Eucl", want_stats=True)
+    got = got.cpu().numpy()
+    assert np.array_equal(got, got.T)
+    for a, b in near:
+        na, nb = int(totals[a]), int(totals[b])
+        num = sum((int(x) * nb - int(y) * na) ** 2 for x, y in zip(counts[a], counts[b]))
+        want = math.sqrt(num) / (na * nb)
+        assert 0 < want < 1e-8 and abs(got[a, b] - want) <= 1e-6 * want, (a, b, got[a, b], want)   # (the quotients c / n are rounded: 1e-16 / 1e-9)
+
+
 @pytest.mark.parametrize("dim", [4096, 16384])
 def test_eucl_three_planes_large_word_space(ctx, dim):
     """Three digit planes at k = 6 / 7: the middle accumulator group adds three digit products per word, so its worst case -
