@@ -709,13 +709,20 @@ def main():
     if dist is not None and world > 1 and not args.no_complete_rows:
         import threading
         finished = threading.Event()
+        emit_lock, emitted = threading.Lock(), [False]
+
+        def emit(error=None):                    # the one JSON line, whoever gets here first (watchdog thread or main thread)
+            with emit_lock:
+                if rank == 0 and not emitted[0]:
+                    emitted[0] = True
+                    if error is not None:
+                        result["config"]["multi_gpu"]["complete_rows_error"] = error
+                    print(json.dumps(result), flush=True)
 
         def watchdog():
             if finished.wait(args.complete_rows_timeout):
                 return
-            if rank == 0:
-                result["config"]["multi_gpu"]["complete_rows_error"] = "no completion within %g s; the ranks left without it" % args.complete_rows_timeout
-                print(json.dumps(result), flush=True)
+            emit("no completion within %g s; the ranks left without it" % args.complete_rows_timeout)
             os._exit(0)
 
         threading.Thread(target=watchdog, daemon=True).start()
@@ -734,14 +741,12 @@ def main():
             if rank == 0:
                 result["config"]["multi_gpu"]["complete_rows_ms"] = float(t.item())
         except Exception as exc:                 # noqa: BLE001 - the record goes out whatever this optional step does
-            if rank == 0:
-                result["config"]["multi_gpu"]["complete_rows_error"] = repr(exc)[:400]
             finished.set()
-            if rank == 0:
-                print(json.dumps(result), flush=True)
+            emit(repr(exc)[:400])
             os._exit(0)                          # a failed collective leaves the group unusable: no barrier, no destroy
         finished.set()
-    if rank == 0:
+        emit()
+    elif rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
