@@ -99,8 +99,9 @@ __global__ __launch_bounds__(256) void prep_planes_kernel(const uint32_t* __rest
     if (mx) atomicMax(&mx_s[rr], mx);
     __syncthreads();
     if (cl == 0) {
-        if (SIGNED) {
+        if (SIGNED) {                                     // Spearman: N = |r2|^2 and 1 / sqrt(N) (inf for a constant record: NaN later, as SciPy gives)
             rs[r] = (double)sq_s[rr];
+            rs[npad + r] = 1.0 / sqrt((double)sq_s[rr]);
         } else {
             const unsigned long long tot = (r < n) ? totals[r] : 0ull;
             const double inv = tot ? 1.0 / (double)tot : 0.0;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void classify_tiles_kernel(po_tile_args A, con
 }
 
 // The distance of a row record and a column record from their exact integer Gram entry G (shared by both tile kernels, so
-// that every path gives the same bits).  Per-record terms - Eucl: t0 = S/n^2, t1 = 1/n, t2 = S (exact);  SC: t0 = N.
+// that every path gives the same bits).  Per-record terms - Eucl: t0 = S/n^2, t1 = 1/n, t2 = S (exact);  SC: t0 = N, t1 = 1/sqrt(N).
 //   Eucl: d^2 = (t0_r + t0_c) + G * ((-2 t1_r) * t1_c): the doubling is exact, so the product of the two per-record factors is
 //   the same number whichever record is the row, and one fused multiply-add replaces multiply, doubling and subtraction
 //   (round 5; five float64 instructions per pair instead of seven).  `same`: the pair is a record with itself.
@@ -213,13 +214,11 @@ __device__ __forceinline__ double gram_i8_value(const double G, const double t0r
         const double v = po_sqrt_nonneg(d2) * scale;
         return same ? 0.0 : v;
     } else {                                               // SC; a constant record has N = 0 -> NaN as SciPy gives
-        // G / sqrt(N_r N_c) as G * rsqrt: v_rsq_f64 seed + two Newton steps (~1 ulp) instead of the
-        // ~40-instruction sqrt + divide; identical records (G = N_r = N_c, exact integers) give exactly 0
+        // 1 - G / sqrt(N_r N_c) as 1 - G (s_r s_c) with s = 1 / sqrt(N) once per record (t1; end of round 5: the per-pair v_rsq_f64 and its
+        // two Newton steps were 10 of ~19 float64-rate instructions of a pair); the product of the two per-record factors is formed first, so
+        // the value does not depend on which record is the row; identical records (G = N_r = N_c, exact integers) give exactly 0
         const double x = t0r * t0c;
-        double y = __builtin_amdgcn_rsq(x);
-        y = fma(0.5 * y, fma(-(x * y), y, 1.0), y);
-        y = fma(0.5 * y, fma(-(x * y), y, 1.0), y);
-        return (G == t0r && G == t0c) ? (x > 0.0 ? 0.0 : G / x) : 1.0 - G * y;
+        return (G == t0r && G == t0c) ? (x > 0.0 ? 0.0 : G / x) : fma(-G, t1r * t1c, 1.0);
     }
 }
 
@@ -265,15 +264,11 @@ __device__ __forceinline__ unsigned long long gram_i8_values_fast(const double (
         for (int e = 0; e < N; ++e) out[e] = (OUT)fma(r[e], h[e], gg[e]);
     } else {
 #pragma unroll
-        for (int e = 0; e < N; ++e) { x[e] = t0r[e] * t0c[e]; special |= __builtin_amdgcn_ballot_w64(G[e] == t0r[e] && G[e] == t0c[e]); }
+        for (int e = 0; e < N; ++e) special |= __builtin_amdgcn_ballot_w64(G[e] == t0r[e] && G[e] == t0c[e]);
 #pragma unroll
-        for (int e = 0; e < N; ++e) y[e] = __builtin_amdgcn_rsq(x[e]);
+        for (int e = 0; e < N; ++e) y[e] = t1r[e] * t1c[e];
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int e = 0; e < N; ++e) y[e] = fma(0.5 * y[e], fma(-(x[e] * y[e]), y[e], 1.0), y[e]);
-#pragma unroll
-        for (int e = 0; e < N; ++e) out[e] = (OUT)(1.0 - G[e] * y[e]);
+        for (int e = 0; e < N; ++e) out[e] = (OUT)fma(-G[e], y[e], 1.0);
     }
     asm volatile("" : "+s"(special));                      // the comparisons are made here, not collected at the end of the caller
     return special;
@@ -293,14 +288,14 @@ __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1
     // the block's first column inside the tile (for the diagonal of the matrix): 64 wc, unless the scratch is a column half of the tile
     const uint32_t ccol = ccol_of_block == 0xFFFFFFFFu ? wc * 64 : ccol_of_block;
     const double* t0r = terms + rrow, *t0c = terms + 128 + wc * 64;             // Eucl: S/n^2      SC: N
-    const double* t1r = terms + 256 + rrow, *t1c = terms + 384 + wc * 64;       // Eucl: 1/n
+    const double* t1r = terms + 256 + rrow, *t1c = terms + 384 + wc * 64;       // Eucl: 1/n        SC: 1/sqrt(N)
     const double* t2r = terms + 512 + rrow, *t2c = terms + 640 + wc * 64;       // Eucl: S
     OUT* wt = tl + (trow + 4 * lh) * STRIDE + wc * 64 + lr;
     // (two planes into a float64 scratch: 96 accumulators and value pairs of two registers each leave no room for the eight registers of
     //  column terms - they are read from the LDS again for every row, behind a lane index the compiler cannot see through)
     constexpr bool kReloadCols = sizeof(OUT) == 8 && P >= 2;
     double tc0 = t0c[lr], tc1 = t0c[32 + lr];
-    double ic0 = METRIC == PO_EUCL ? t1c[lr] : 0.0, ic1 = METRIC == PO_EUCL ? t1c[32 + lr] : 0.0;
+    double ic0 = t1c[lr], ic1 = t1c[32 + lr];                      // Eucl: 1/n      SC: 1/sqrt(N)
     auto gram = [&](const int nn, const int reg) -> double {
         double G = (double)g[NG - 1][nn][reg];         // Horner in 128: every partial sum an exact integer below 2^53
 #pragma unroll
@@ -316,7 +311,7 @@ __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1
             uint32_t lrx = lr;
             asm volatile("" : "+v"(lrx));
             tc0 = t0c[lrx]; tc1 = t0c[32 + lrx];
-            if (METRIC == PO_EUCL) { ic0 = t1c[lrx]; ic1 = t1c[32 + lrx]; }
+            ic0 = t1c[lrx]; ic1 = t1c[32 + lrx];
         }
 #pragma unroll
         for (int e = 0; e < kIlpRows; ++e) {
@@ -324,7 +319,7 @@ __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1
             const uint32_t rl = (reg & 3) + 8 * ((reg - REG0) >> 2) + 4 * lh;
             G[2 * e] = gram(0, reg); G[2 * e + 1] = gram(1, reg);
             a0[2 * e] = a0[2 * e + 1] = t0r[rl];
-            a1[2 * e] = a1[2 * e + 1] = METRIC == PO_EUCL ? t1r[rl] : 0.0;
+            a1[2 * e] = a1[2 * e + 1] = t1r[rl];
             b0[2 * e] = tc0; b0[2 * e + 1] = tc1;
             b1[2 * e] = ic0; b1[2 * e + 1] = ic1;
         }
@@ -379,8 +374,7 @@ __device__ __forceinline__ void gram_i8_values_to_tile(const v16i (&g)[2 * P - 1
             for (int nn = 0; nn < 2; ++nn) {
                 const uint32_t cl = 32 * nn + lrc;
                 const double G = NG >= 3 ? Gs[NG >= 3 ? reg - REG0 : 0][nn] : gram_again(nn, reg);
-                wp[32 * nn] = (OUT)gram_i8_value<METRIC>(G, t0r[rl], METRIC == PO_EUCL ? t1r[rl] : 0.0, t2r + rl, t0c[cl],
-                                                          METRIC == PO_EUCL ? t1c[cl] : 0.0, t2c + cl, diag_tile && rrow + rl == ccol + cl);
+                wp[32 * nn] = (OUT)gram_i8_value<METRIC>(G, t0r[rl], t1r[rl], t2r + rl, t0c[cl], t1c[cl], t2c + cl, diag_tile && rrow + rl == ccol + cl);
                 __builtin_amdgcn_sched_barrier(0);         // (one value after the other: their exact branches are long)
             }
         }
@@ -476,7 +470,7 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
     if (t_e < 256) {
         const uint64_t rec = (t_e < 128) ? i0 + t_e : j0 + (t_e - 128);
         terms[t_e] = rs[rec];
-        terms[256 + t_e] = METRIC == PO_EUCL ? rs[A.npad + rec] : 0.0;
+        terms[256 + t_e] = rs[A.npad + rec];
         terms[512 + t_e] = METRIC == PO_EUCL ? rs[2 * A.npad + rec] : 0.0;
     }
     __syncthreads();
@@ -490,7 +484,7 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
     // the distance of row record iw + rl and column record jw + cl from their exact integer Gram entry
     const bool diag_tile = ti == tj;
     auto value = [&](const double G, const uint32_t rl, const uint32_t cl, const double tc, const double ic) -> double {
-        return gram_i8_value<METRIC>(G, t0r[rl], METRIC == PO_EUCL ? t1r[rl] : 0.0, t2r + rl, tc, ic, t2c + cl,
+        return gram_i8_value<METRIC>(G, t0r[rl], t1r[rl], t2r + rl, tc, ic, t2c + cl,
                                      diag_tile && wr * 32 + rl == wc * 64 + cl);
     };
     auto gram = [&](const int nn, const int reg) -> double {
@@ -514,7 +508,7 @@ __global__ __launch_bounds__(kThreads, P == 1 ? 4 : 2) void gram_i8_tile_kernel(
 #pragma unroll
         for (int nn = 0; nn < 2; ++nn) {
             const uint64_t c = jw + nn * 32 + lr_e;
-            const double tc = t0c[nn * 32 + lr_e], ic = METRIC == PO_EUCL ? t1c[nn * 32 + lr_e] : 0.0;
+            const double tc = t0c[nn * 32 + lr_e], ic = t1c[nn * 32 + lr_e];
             const bool c_ok = c >= A.col_begin && c < n_cols;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -573,7 +567,7 @@ __global__ __launch_bounds__(kQuadThreads, 4) void gram_i8_quad_kernel(po_tile_a
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const uint32_t idx = wave * 2 + u, a = idx >> 1, side = idx & 1;   // six (Eucl) or two (SC) one-KiB instructions
-        if (idx < (METRIC == PO_EUCL ? 6u : 2u))
+        if (idx < (METRIC == PO_EUCL ? 6u : 4u))
             po_glds16(rs + a * A.npad + (side ? j0 : i0) + 2 * lane, reinterpret_cast<unsigned char*>(terms + a * 256 + side * 128));
     }
 
@@ -742,7 +736,7 @@ __global__ __launch_bounds__(kHalfThreads, 4) void gram_i8_half_kernel(po_tile_a
     if (t_e < 192) {
         const uint64_t rec = (t_e < 128) ? i0 + t_e : j0 + (t_e - 128);
         terms[t_e] = rs[rec];
-        terms[256 + t_e] = METRIC == PO_EUCL ? rs[A.npad + rec] : 0.0;
+        terms[256 + t_e] = rs[A.npad + rec];
         terms[512 + t_e] = METRIC == PO_EUCL ? rs[2 * A.npad + rec] : 0.0;
     }
     __syncthreads();
