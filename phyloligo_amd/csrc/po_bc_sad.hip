@@ -138,15 +138,27 @@ __global__ __launch_bounds__(kThreads, 2) void bc_sad_tile_kernel(po_tile_args A
     double wi[8];
 #pragma unroll
     for (int ia = 0; ia < 8; ++ia) wi[ia] = st1[i0 + ty * 8 + ia];
+    double wj[8];
+#pragma unroll
+    for (int ib = 0; ib < 8; ++ib) wj[ib] = st1[min(j0 + 32 * (ib >> 1) + 2 * tx + (ib & 1), A.npad - 1)];
+    // Every record of a profile matrix has sum f = 1 exactly (its counts add up to its total), so the denominator is 2 and the float64
+    // division of every pair - a reciprocal and a dozen dependent instructions, a third of this kernel's vector work at 136 words - is a
+    // scaling by 1/2, which gives the same bits.  Checked per wave on the terms themselves; anything else (empty records, edited
+    // profiles) divides as before.
+    bool unit = true;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) unit = unit && wi[q] == 1.0 && wj[q] == 1.0;
+    const bool halve = __builtin_amdgcn_ballot_w64(!unit) == 0ull;
+    const double half_inv_n = 0.5 * inv_n;
     double v[8][8];
 #pragma unroll
     for (int ib = 0; ib < 8; ++ib) {
         const uint64_t j = min(j0 + 32 * (ib >> 1) + 2 * tx + (ib & 1), A.npad - 1);
-        const double wj = st1[j];
 #pragma unroll
         for (int ia = 0; ia < 8; ++ia) {
             const uint64_t i = i0 + ty * 8 + ia;
-            v[ia][ib] = (i == j) ? 0.0 : ((double)acc[ia][ib] * inv_n) / (wi[ia] + wj);
+            const double x = halve ? (double)acc[ia][ib] * half_inv_n : ((double)acc[ia][ib] * inv_n) / (wi[ia] + wj[ib]);
+            v[ia][ib] = (i == j) ? 0.0 : x;
         }
     }
     if constexpr (sizeof(OUT) == 4) po_store_block_f32<8, kThreads>(A, ti, tj, i0, j0, tx, ty, v, reinterpret_cast<float*>(smem));

@@ -185,6 +185,14 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
     double* wl = reinterpret_cast<double*>(smem) + wv * (32 * kTrStride);
     const double* r0t = terms + wr * 128, *c0t = terms + TR + wave * 64;
     const double* r1t = terms + TR + TE + wr * 128, *c1t = terms + TR + TE + TR + wave * 64;
+    // BC: every record of a profile matrix has sum f = 1 exactly, the denominator is 2 and the division a scaling by 1/2 with the same
+    // bits (po_bc_sad.hip); checked per wave on its 128 row and 64 column terms
+    bool halve = false;
+    if (EPI != EPI_KT) {
+        const uint32_t ln = lh * 32 + lr;
+        halve = __builtin_amdgcn_ballot_w64(!(r0t[ln] == 1.0 && r0t[64 + ln] == 1.0 && c0t[ln] == 1.0)) == 0ull;
+    }
+    const double half_scalar = 0.5 * E.scalar;
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
         const uint64_t c = jw + nn * 32 + lr;
@@ -202,7 +210,8 @@ __global__ __launch_bounds__(kThreads, 2) void pairdot_tile_kernel(po_tile_args 
                     v = po_kt_value(G, r0t[m * 32 + rl], tc0, r1t[m * 32 + rl], tc1);
                 } else {                      // BC = (sum |ca - cb| / n) / (w_a + w_b),  sum |ca - cb| = s_a + s_b - 2 sum min
                     const double num = (r1t[m * 32 + rl] + tc1) - 2.0 * G;      // exact integers
-                    v = (r == c) ? 0.0 : (num * E.scalar) / (r0t[m * 32 + rl] + tc0);
+                    const double x = halve ? num * half_scalar : (num * E.scalar) / (r0t[m * 32 + rl] + tc0);
+                    v = (r == c) ? 0.0 : x;
                 }
                 if (c_ok && r >= A.row_begin && r < n_rows) po_out_store(&out[(r - A.row_begin) * A.ld_out + (c - A.col_begin)], (OUT)v);
                 if (mirror) wl[lr * kTrStride + rl] = v;
