@@ -119,6 +119,94 @@ __global__ __launch_bounds__(kThreads) void row_order_kernel(const T* __restrict
     if (t == 0) rowstat[3 * npad + r] = (double)(tied / 2);
 }
 
+// The same for integer counts of up to 1 024 words (k <= 5) with ONE WAVE per record, four records per workgroup and no workgroup barrier
+// (end of round 5): at D = 256 the kernel above spends a 256-lane workgroup, 64 KiB of LDS and sixteen barriers on a record - 348 us for
+// 50 000 records, 0.35 of the 2.5 ms a float32 Spearman matrix takes.  A lane holds the words lane, lane + 64, ... in registers; counts
+// below 1 024 go through the wave's own histogram (4 KiB) and its prefix sum (a scan over the lanes), larger ones (contigs beyond ~40 kb
+// at k = 4) through the all-pairs comparison inside the wave.  Same integers out.
+constexpr uint32_t kWaveBins = 1024, kWaveDim = 1024;
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(kThreads) void row_order_wave_kernel(const uint32_t* __restrict__ rows, uint64_t n, uint32_t dim,
+                                                                  uint64_t npad, double* __restrict__ rt,
+                                                                  uint32_t* __restrict__ lessrank, int32_t* __restrict__ r2,
+                                                                  double* __restrict__ rowstat) {
+    __shared__ uint32_t lds[kThreads / 64][2 * kWaveBins];              // per wave: hist | pref   (all-pairs path: the record's values)
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t r = (uint64_t)blockIdx.x * (kThreads / 64) + wave;
+    if (r >= n) return;                                                 // (no workgroup barrier below)
+    uint32_t* hist = lds[wave];
+    uint32_t* pref = hist + kWaveBins;
+    const uint32_t* row = rows + r * dim;
+    constexpr int W = kWaveDim / 64;
+    uint32_t val[W];
+    uint32_t mx = 0;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const uint32_t d = lane + 64u * i;
+        val[i] = d < dim ? row[d] : 0u;
+        mx = max(mx, val[i]);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    unsigned long long my_tied = 0;
+    auto emit = [&](uint32_t d, uint32_t less, uint32_t equal) {
+        if (rt) rt[(uint64_t)d * npad + r] = (double)less + 0.5 * ((double)equal - (double)dim);
+        if (lessrank) lessrank[r * dim + d] = less;
+        if (r2) r2[r * dim + d] = (int32_t)(2u * less + equal) - (int32_t)dim;
+        my_tied += equal - 1;
+    };
+    if (mx < kWaveBins) {
+        const uint32_t nv = mx + 1;
+        for (uint32_t v = lane; v < nv; v += 64) hist[v] = 0;
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            if (lane + 64u * i < dim) atomicAdd(&hist[val[i]], 1u);
+        wave_lds_sync();
+        const uint32_t seg = (nv + 63u) / 64u;
+        const uint32_t v0 = min(lane * seg, nv), v1 = min(v0 + seg, nv);
+        uint32_t ssum = 0;
+        for (uint32_t v = v0; v < v1; ++v) ssum += hist[v];
+        uint32_t incl = ssum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)incl, o, 64);
+            if ((int)lane >= o) incl += u;
+        }
+        uint32_t run = incl - ssum;
+        for (uint32_t v = v0; v < v1; ++v) { pref[v] = run; run += hist[v]; }
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const uint32_t d = lane + 64u * i;
+            if (d < dim) emit(d, pref[val[i]], hist[val[i]]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            if (lane + 64u * i < dim) hist[lane + 64u * i] = val[i];
+        wave_lds_sync();
+#pragma unroll 1
+        for (int i = 0; i < W; ++i) {
+            const uint32_t d = lane + 64u * i;
+            if (d >= dim) break;
+            const uint32_t x = val[i];
+            uint32_t less = 0, equal = 0;
+            for (uint32_t q = 0; q < dim; ++q) {
+                const uint32_t y = hist[q];
+                less += (y < x);
+                equal += (y == x);
+            }
+            emit(d, less, equal);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) my_tied += __shfl_down(my_tied, o, 64);
+    if (lane == 0) rowstat[3 * npad + r] = (double)(my_tied / 2);
+}
+
 __global__ __launch_bounds__(kThreads) void zero_pad_kernel(double* __restrict__ rt, uint64_t n, uint32_t dim,
                                                             uint64_t npad) {
     const uint64_t pad = npad - n;
@@ -190,7 +278,10 @@ int po_launch_ranks(po_ctx* ctx, const uint32_t* d_counts, const double* d_freq,
         hipLaunchKernelGGL(zero_pad_kernel, dim3(256), dim3(kThreads), 0, ctx->stream, d_rt, n, dim, npad);
         PO_CHECK_LAUNCH("zero_pad_kernel");
     }
-    if (d_counts) {
+    if (d_counts && dim <= kWaveDim) {
+        hipLaunchKernelGGL(row_order_wave_kernel, dim3((uint32_t)((n + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0, ctx->stream,
+                           d_counts, n, dim, npad, d_rt, d_lessrank, d_r2, d_rowstat);
+    } else if (d_counts) {
         auto k = row_order_kernel<uint32_t, true>;
         const size_t shmem = 2 * kValueBins * sizeof(uint32_t);
         PO_SHMEM(ctx, k, shmem);
