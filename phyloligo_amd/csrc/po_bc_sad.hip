@@ -27,17 +27,25 @@ __global__ __launch_bounds__(256) void prep_pack8_kernel(const uint32_t* __restr
     const uint64_t n0 = (uint64_t)blockIdx.x * 64;
     const uint32_t g0 = blockIdx.y * 64;
     const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const bool vec = (dim & 3u) == 0u && (reinterpret_cast<uintptr_t>(counts) & 15u) == 0u;
     uint32_t mx = 0;
     for (uint32_t r = ty; r < 64; r += 4) {                        // r: record, tx: group
         const uint64_t row = n0 + r;
         uint32_t packed = 0;
         const uint32_t d = (g0 + tx) * 4;
         if (row < n) {
+            uint32_t v4[4] = {0u, 0u, 0u, 0u};
+            if (vec && d + 3 < dim) {                                   // one 16-byte load (rows of 4 k words from an aligned base)
+                const uint4 q = *reinterpret_cast<const uint4*>(counts + row * dim + d);
+                v4[0] = q.x; v4[1] = q.y; v4[2] = q.z; v4[3] = q.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = (d + e < dim) ? counts[row * dim + d + e] : 0u;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint32_t v = (d + e < dim) ? counts[row * dim + d + e] : 0u;
-                mx = max(mx, v);
-                packed |= min(v, 255u) << (8 * e);
+                mx = max(mx, v4[e]);
+                packed |= min(v4[e], 255u) << (8 * e);
             }
         }
         tile[r][tx] = packed;

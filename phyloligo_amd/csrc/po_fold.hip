@@ -66,20 +66,56 @@ __global__ __launch_bounds__(256) void rc_fold_kernel(const T* __restrict__ in, 
     if (threadIdx.x < 16) { sum_s[threadIdx.x] = 0; max_s[threadIdx.x] = 0; }
     const uint64_t row0 = (uint64_t)blockIdx.x * rpb;
     const uint32_t rows = (uint32_t)min((uint64_t)rpb, n - row0);
+    // Where word i of a record sits in the LDS copy.  The partner reads of a wave - rc(w) for 64 consecutive representatives w - differ in
+    // their HIGH digits only (the reversed low digits of w) and would all fall into one bank: 64-way conflicts made this pass LDS-bound
+    // (432 us at k = 6 whatever the arithmetic around it).  Folding the bits above the bank bits into them - a permutation inside every
+    // group of 64 words - spreads both the representatives and their partners over the banks.
+    auto slot = [](uint32_t i) { return i ^ ((i >> 6) & 63u) ^ ((i >> 12) & 63u); };
+    // the plan's two tables come into LDS with the records: read from global memory word by word inside the fold loop they are a chain of
+    // dependent L2 round trips per lane (eight at k = 6)
+    // (up to 1 024 folded words; beyond, the 16 KiB they would take cost more in resident workgroups than the round trips)
+    const bool tables_in_lds = dim_f <= 1024u;
+    uint32_t* lsrc = reinterpret_cast<uint32_t*>(smem + (size_t)rpb * dim * sizeof(T));
+    if (tables_in_lds)
+        for (uint32_t e = threadIdx.x; e < 2u * dim_f; e += 256) lsrc[e] = src[e];
+    const uint32_t* tsrc = tables_in_lds ? lsrc : src;
     const T* x = in + row0 * dim;
-    for (uint32_t e = threadIdx.x; e < rows * dim; e += 256) rec[e] = x[e];
+    const uint32_t dmask = dim - 1u;                       // dim = 4^k
+    constexpr uint32_t per16 = 16u / (uint32_t)sizeof(T);
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0u && dim >= per16) {     // 16 bytes per lane and load
+        const uint4* x4 = reinterpret_cast<const uint4*>(x);
+        for (uint32_t e = threadIdx.x; e < rows * dim / per16; e += 256) {
+            const uint4 q = x4[e];
+            const T* qv = reinterpret_cast<const T*>(&q);
+#pragma unroll
+            for (uint32_t u = 0; u < per16; ++u) {
+                const uint32_t g = e * per16 + u, i = g & dmask;
+                rec[(g - i) + slot(i)] = qv[u];
+            }
+        }
+    } else {
+        for (uint32_t e = threadIdx.x; e < rows * dim; e += 256) {
+            const uint32_t i = e & dmask;
+            rec[(e - i) + slot(i)] = x[e];
+        }
+    }
     __syncthreads();
     bool sym = true;
     T* y = out + row0 * dim_f;
-    for (uint32_t e = threadIdx.x; e < rows * dim_f; e += 256) {
-        const uint32_t r = e / dim_f, d = e - r * dim_f;
-        const uint32_t w = src[d];
-        T v = (T)0;
-        if (w != 0xFFFFFFFFu) {
-            v = rec[r * dim + w];
-            sym = sym && (v == rec[r * dim + rc_word(w, k)]);
+    // a lane takes folded columns (the source word and its reverse complement come from the plan's tables: src[dim_f .. 2 dim_f) holds
+    // rc_word(src[d]); round 5 - the k-step loop per element and a 32-bit division made this pass vector-ALU bound at k = 6) and walks the
+    // workgroup's records: consecutive lanes write consecutive words of a record
+    for (uint32_t d = threadIdx.x; d < dim_f; d += 256) {
+        const uint32_t w = tsrc[d], wr = tsrc[dim_f + d];
+        const uint32_t sw = slot(w), swr = slot(wr);
+        for (uint32_t r = 0; r < rows; ++r) {
+            T v = (T)0;
+            if (w != 0xFFFFFFFFu) {
+                v = rec[r * dim + sw];
+                sym = sym && (v == rec[r * dim + swr]);
+            }
+            y[r * dim_f + d] = v;
         }
-        y[e] = v;
     }
     if (!sym) atomicOr(asym, PO_FOLD_ASYM);
     // integer counts: can every 128-record block take the equal-total fast path (po_jsd_lut.hip / po_bc_sad.hip)?
@@ -95,8 +131,16 @@ __global__ __launch_bounds__(256) void rc_fold_kernel(const T* __restrict__ in, 
                 sum += v;
                 mx = max(mx, v);
             }
-            atomicAdd(&sum_s[r], sum);
-            atomicMax(&max_s[r], mx);
+            // (a record's threads are whole waves or aligned parts of one - tpr is a power of two: partial sums meet inside the wave first,
+            //  256 atomics on one LDS word are 256 turns)
+            for (uint32_t o = min(tpr, 64u) / 2; o > 0; o >>= 1) {
+                sum += __shfl_down(sum, o, 64);
+                mx = max(mx, (uint32_t)__shfl_down((int)mx, o, 64));
+            }
+            if ((j & 63u) == 0u) {
+                atomicAdd(&sum_s[r], sum);
+                atomicMax(&max_s[r], mx);
+            }
         }
         __syncthreads();
         if (j == 0 && r < rows) {
@@ -171,8 +215,12 @@ int launch_fold(po_ctx* ctx, const T* in, uint64_t n, uint32_t dim, uint32_t k, 
                 T* out, uint32_t* asym, const unsigned long long* totals) {
     const size_t row_bytes = (size_t)dim * sizeof(T);
     if (row_bytes <= 32768) {
-        const uint32_t rpb = (uint32_t)(32768 / row_bytes > 16 ? 16 : 32768 / row_bytes);
-        hipLaunchKernelGGL(rc_fold_kernel<T>, dim3((uint32_t)((n + rpb - 1) / rpb)), dim3(256), rpb * row_bytes, ctx->stream,
+        // records per workgroup: 16 KiB of them (a streaming pass lives on resident workgroups: 32 KiB measured 403 us at k = 6, 16 KiB ...)
+        const uint32_t cap = row_bytes <= 16384 ? 16384u : 32768u;
+        const uint32_t rpb = (uint32_t)(cap / row_bytes > 16 ? 16 : cap / row_bytes);
+        const size_t shmem = rpb * row_bytes + (dim_f <= 1024u ? 2 * (size_t)dim_f * sizeof(uint32_t) : 0);       // records + the plan's two tables
+        PO_SHMEM(ctx, rc_fold_kernel<T>, shmem);
+        hipLaunchKernelGGL(rc_fold_kernel<T>, dim3((uint32_t)((n + rpb - 1) / rpb)), dim3(256), shmem, ctx->stream,
                            in, n, dim, k, src, dim_f, rpb, out, asym, totals);
     } else {
         hipLaunchKernelGGL(rc_fold_long_kernel<T>, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, ctx->stream, in, n, dim, k,
@@ -228,10 +276,12 @@ static int fold_plan(po_ctx* ctx, uint32_t dim, uint32_t gran, uint32_t* dim_f, 
         ctx->fold_dbl_at = 0xFFFFFFFFu;
         return PO_OK;
     }
-    std::vector<uint32_t> src(ppad + spad, 0xFFFFFFFFu);
+    std::vector<uint32_t> src(2 * (size_t)(ppad + spad), 0xFFFFFFFFu);     // [source word of every folded column | its reverse complement]
     if (selfs_first) std::swap(pairs, selfs);            // first region: self-paired words, second: representatives
     for (size_t i = 0; i < pairs.size(); ++i) src[i] = pairs[i];
     for (size_t i = 0; i < selfs.size(); ++i) src[ppad + i] = selfs[i];
+    for (size_t i = 0; i < (size_t)(ppad + spad); ++i)
+        if (src[i] != 0xFFFFFFFFu) src[ppad + spad + i] = rc_word(src[i], k);
     int rc = po_buf_reserve(ctx, &ctx->ws_fold_src, src.size() * sizeof(uint32_t));
     if (rc) return rc;
     PO_HIP(hipMemcpyAsync(ctx->ws_fold_src.p, src.data(), src.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
