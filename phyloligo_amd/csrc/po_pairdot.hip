@@ -560,20 +560,30 @@ __global__ __launch_bounds__(256) void bc_emap_kernel(const uint32_t* __restrict
     for (uint32_t t = 1; t <= T; ++t) emap[o + t - 1] = (t << 20) | w;
 }
 
-// s[r] = sum of the counts of record r over ALL words (folded: representatives count twice)
+// s[r] = sum of the counts of record r over ALL words (folded: representatives count twice).  64 records per workgroup, four lanes
+// per record each walking every fourth word group (one thread per record walked 520 groups in a row at k = 6, with 196 workgroups
+// on 256 CUs: 140 us for 104 MB).
 __global__ __launch_bounds__(256) void bc_rowsum_kernel(const uint32_t* __restrict__ p8t, uint32_t groups, uint32_t dbl_group,
                                                         uint64_t n, uint64_t npad, uint64_t out_n, double* __restrict__ s) {
-    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= out_n) return;
+    __shared__ unsigned long long part[2][4][64];
+    const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const uint64_t r = (uint64_t)blockIdx.x * 64 + tx;
     unsigned long long a = 0, b = 0;
     if (r < n) {
-        for (uint32_t g = 0; g < groups; ++g) {
+        for (uint32_t g = ty; g < groups; g += 4) {
             const uint32_t v = p8t[(uint64_t)g * npad + r];
             const uint32_t sum = (v & 255u) + ((v >> 8) & 255u) + ((v >> 16) & 255u) + (v >> 24);
             if (g < dbl_group) a += sum; else b += sum;
         }
     }
-    s[r] = (double)(2ull * a + b);
+    part[0][ty][tx] = a;
+    part[1][ty][tx] = b;
+    __syncthreads();
+    if (ty == 0 && r < out_n) {
+        a = part[0][0][tx] + part[0][1][tx] + part[0][2][tx] + part[0][3][tx];
+        b = part[1][0][tx] + part[1][1][tx] + part[1][2][tx] + part[1][3][tx];
+        s[r] = (double)(2ull * a + b);
+    }
 }
 
 // thread = (record, chunk): EPC thermometer bits of one record
@@ -656,7 +666,7 @@ int po_launch_bc_thermo_prep(po_ctx* ctx, const uint32_t* p8t, uint32_t groups_p
     hipLaunchKernelGGL(bc_emap_kernel, dim3((words + 255) / 256), dim3(256), 0, ctx->stream, colmax, off, words, emap);
     PO_CHECK_LAUNCH("bc_emap_kernel");
     const uint32_t dbl_group = dbl_at == PO_NO_DOUBLING ? 0u : dbl_at / 4;     // unfolded: every word counts once (class b)
-    hipLaunchKernelGGL(bc_rowsum_kernel, dim3((uint32_t)((op_n + 255) / 256)), dim3(256), 0, ctx->stream, p8t, groups_pad,
+    hipLaunchKernelGGL(bc_rowsum_kernel, dim3((uint32_t)((op_n + 63) / 64)), dim3(256), 0, ctx->stream, p8t, groups_pad,
                        dbl_group, n, npad, op_n, rowsum);
     PO_CHECK_LAUNCH("bc_rowsum_kernel");
     const uint32_t n_chunks = (uint32_t)(kpad / epc);
