@@ -70,8 +70,8 @@ def first_contact(stage, fn, *args, **kwargs):
         out.write(json.dumps(line) + "\n")
         out.flush()
         if rank != 0:                                    # the launcher takes every rank down when the first one exits: leave
-            import time                                  # rank 0 - which usually fails for the same reason at the same moment -
-            time.sleep(3.0)                              # the time to get its line out
+            import time                                  # rank 0 - which usually fails for the same reason, but may still be
+            time.sleep(15.0)                             # importing torch on a loaded host - the time to get its line out
         sys.exit(3)
 
 
